@@ -1,0 +1,104 @@
+"""TEST INFRASTRUCTURE ONLY (oracle/): run the flang-built reference binary.
+
+Helpers to run `oracle/_ref/N<mesh>/C2Ray_3D_{test,tap}` (built from the sources
+under /root/reference by oracle/ref_build.sh) in a scratch run directory and to
+read back what it wrote.  Nothing here is imported by the product package.
+
+Run-time inputs of the reference test target:
+  stdin/file lines: 5 stream flags (files_for_3D/output.F90:90), T0
+  (mat_ini_test.F90:126), isothermal y/n (:130), restart y/n (:142), midpoint
+  y/n (:154), start slice (:157), steps per slice, outputs per slice
+  (time_ini.F90:48-53); ./test_sources.dat (sourceprops_test.F90:112-166);
+  ../tables/*.tab (cooling_h.f90:83-149) when not isothermal.
+"""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REFDIR = HERE / "_ref"
+
+_KINDS = {1: np.int32, 2: np.float32, 3: np.float64}
+
+
+def read_records(path) -> dict:
+    """Read a tap dump (see oracle/probe/evolve_tap.f90 for the record layout)."""
+    out = {}
+    data = Path(path).read_bytes()
+    off = 0
+    while off < len(data):
+        name = data[off:off + 16].decode().strip()
+        kind, count = struct.unpack_from("<iq", data, off + 16)
+        off += 28
+        dt = np.dtype(_KINDS[kind])
+        out[name] = np.frombuffer(data, dtype=dt, count=count, offset=off).copy()
+        off += count * dt.itemsize
+    return out
+
+
+def ref_binary(mesh: int, which: str = "tap", omp: bool = False) -> Path:
+    tag = f"N{mesh}" + ("_omp" if omp else "")
+    return REFDIR / tag / f"C2Ray_3D_{which}"
+
+
+def run_reference(mesh: int, sources, *, T0=1e4, isothermal=True, steps_per_slice=1,
+                  outputs_per_slice=1, which="tap", omp=False, name=None, threads=1,
+                  timeout=3600, keep=True):
+    """Run the reference; returns the run directory (results in <run>/results)."""
+    exe = ref_binary(mesh, which, omp)
+    if not exe.exists():
+        raise FileNotFoundError(f"{exe} missing: run oracle/ref_build.sh {mesh}")
+    name = name or f"run_N{mesh}_{'iso' if isothermal else 'heat'}_{len(sources)}src"
+    run = REFDIR / name
+    if run.exists():
+        shutil.rmtree(run)
+    (run / "results").mkdir(parents=True)
+    with open(run / "test_sources.dat", "w") as f:
+        f.write(f"{len(sources)}\n")
+        for (i, j, k, s) in sources:
+            f.write(f"{i} {j} {k} {s:.6e}\n")
+    with open(run / "input", "w") as f:
+        f.write("0 1 1 0 0\n")
+        f.write(f"{T0:g}\n")
+        f.write("y\n" if isothermal else "n\n")
+        f.write("n\nn\n1\n")
+        f.write(f"{steps_per_slice}\n{outputs_per_slice}\n")
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = str(threads)
+    llvm_lib = "/opt/rocm/lib/llvm/lib"
+    env["LD_LIBRARY_PATH"] = llvm_lib + ":" + env.get("LD_LIBRARY_PATH", "")
+    with open(run / "stdout.txt", "w") as so:
+        subprocess.run([str(exe), "input"], cwd=run, env=env, stdout=so,
+                       stderr=subprocess.STDOUT, timeout=timeout, check=True)
+    return run
+
+
+def parse_log(run) -> list[list[int]]:
+    """Non-converged counts per outer iteration, one list per evolve3D call
+    (files_for_3D/evolve.F90:488 'Number of non-converged points')."""
+    calls, cur = [], None
+    for line in (Path(run) / "results" / "C2Ray.log").read_text(errors="replace").splitlines():
+        if line.startswith("Time, dt:") or "Time, dt:" in line:
+            cur = []
+            calls.append(cur)
+        m = re.search(r"Number of non-converged points:\s+(\d+)", line)
+        if m and cur is not None:
+            cur.append(int(m.group(1)))
+    return calls
+
+
+def iteration_times(run) -> list[float]:
+    """Wall-clock stamps 'Time after iteration' from Timings.log (evolve.F90:220)."""
+    out = []
+    for line in (Path(run) / "results" / "Timings.log").read_text(errors="replace").splitlines():
+        m = re.search(r"Time after iteration\s+(\d+)\s*:\s*([\d.]+)", line)
+        if m:
+            out.append(float(m.group(2)))
+    return out
