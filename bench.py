@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cell-updates/s of the evolve3D hot path on a synthetic 256^3 box
+(BASELINE.json configs[2]: 256^3 uniform density, 8 sources, 1 MI355X).
+
+A "step" is ONE outer iteration of evolve3D (files_for_3D/evolve.F90:185-217): set_rates_to_zero,
+pass_all_sources (column sweep + rates for every source of this rank), the sum of the rate grids over
+ranks when N > 1, and the global chemistry pass.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank sweeps --sources sources
+(weak scaling: per-GPU work fixed), the rate grids are all-reduced over RCCL, chemistry is replicated
+as in the reference.  value = mesh^3 x (sources x N) x K / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+SWEEP_BYTES_PER_CELL_SOURCE = 136.0   # SURVEY.md section 8(d), isothermal sweep (evolve0D)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0):
+    """Synthetic inputs of BASELINE configs[2]: uniform density of the
+    reference's test problem at z = 9, isothermal 1e4 K, sources at seeded positions
+    (numpy default_rng(12345), integers in [1, n]) of 1e56 photons/s each.  The gas starts highly
+    ionised (x_HI ~ 1e-3) so that every source's sub-boxes run to the full box: swept cells ==
+    mesh^3 per source, the regime the metric is defined on."""
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    rng = np.random.default_rng(seed)
+    allpos = rng.integers(1, n + 1, size=(first_source + nsrc, 3)).astype(np.int32)
+    srcpos = allpos[first_source:]
+    ndens = np.full(nc, hp.test_density(zred))
+    x0 = 1.0e-3 * (1.0 + 0.5 * np.sin(np.arange(nc, dtype=np.float64) * 1.0e-3))  # neutral fraction
+    xh = np.concatenate([x0, 1.0 - x0])
+    xhe = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
+    mat = pkg.Material(ndens, xh, xhe, None, True, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, np.full(nsrc, 1.0e56 / 1.0e48), 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    return mat, grid, src, cosmo
+
+
+def cpu_baseline(pkg, mesh=96, nsrc=2):
+    """The oracle (single-threaded C port of the reference's path) on a bounded sample of the same
+    workload: one outer iteration on a mesh^3 box with nsrc sources.  Reported, not a target."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as orc
+    orc.build()
+    mat, grid, src, cosmo = config3_inputs(pkg, mesh, nsrc)
+    with np.load(pkg.evolve.DEFAULT_TABLES) as t:
+        T = orc.Tables({k: t[k] for k in t.files})
+    st = orc.Step(grid.mesh, grid.dr, grid.vol, cosmo.zred, cosmo.H0, cosmo.Omega0, 1, 1.0e4, 1.0, src.srcpos,
+                  src.NormFlux, src.S_star, mat.ndens, mat.reccoef)
+    s = orc.State(st, mat.xh, mat.xhe)
+    orc.begin_step(s)
+    t0 = time.perf_counter()
+    orc.pass_all_sources(T, st, s)
+    orc.global_pass(T, st, s, 1.0e7 * pkg.hostphys.YEAR)
+    dt = time.perf_counter() - t0
+    return {"value": mesh ** 3 * nsrc / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{mesh}^3 box, {nsrc} sources, 1 outer iteration (sweep + chemistry), {dt:.1f} s of CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mesh", type=int, default=256)
+    ap.add_argument("--sources", type=int, default=8, help="sources per GPU")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    pkg = ge.load_package()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        comm = pkg.parallel.TorchComm()
+
+    n = a.mesh
+    total_src = a.sources * world
+    # every rank holds the full source list; rank r sweeps r+1, r+1+world, ... (master_slave.F90:85)
+    mat, grid, src, cosmo = config3_inputs(pkg, n, total_src)
+    tables = pkg.RadiationTables.load()
+    e = pkg.HipEngine((n, n, n), local)
+    e.set_tables(tables)
+    e.set_step(mat, grid, cosmo)
+    e.set_sources(src)
+    e.upload_state(mat)
+    e.set_batch(a.batch)
+    e.enable_timing(True)
+    if comm is not None:
+        e.use_torch_rates_buffer(f"cuda:{local}")
+    dt = 1.0e7 * pkg.hostphys.YEAR
+    e.begin_step()
+
+    def step():
+        e.set_rates_to_zero()
+        e.pass_sources(1 + rank, world)
+        if comm is not None:
+            comm.allreduce_rates(e)
+        return e.global_pass(dt)
+
+    def barrier():
+        e.synchronize()
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    sweep_ms = rates_ms = chem_ms = 0.0
+    swept = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        tm = e.timing()
+        sweep_ms += tm.sweep_ms
+        rates_ms += tm.rates_ms
+        chem_ms += tm.chem_ms
+        swept += tm.cells_swept
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        sw = torch.tensor([float(swept)], dtype=torch.float64, device=f"cuda:{local}")
+        comm.dist.all_reduce(sw)
+        swept_total = int(sw.item())
+    else:
+        swept_total = swept
+
+    if rank == 0:
+        units = n ** 3 * total_src * a.steps
+        coverage = swept_total / units
+        rates_per_launch_ms = rates_ms / max(1, a.steps * ((a.sources + a.batch - 1) // a.batch))
+        units_per_launch = n ** 3 * min(a.batch, a.sources)
+        achieved = SWEEP_BYTES_PER_CELL_SOURCE * units_per_launch / (rates_per_launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "cell-updates/sec (grid_cells x sources x iters / wall) on 256^3 box; % HBM roofline",
+            "value": units / elapsed, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: {n}^3 uniform density, {a.sources} sources per GPU "
+                                   f"({total_src} total), isothermal 1e4 K, one evolve3D outer iteration per step",
+                       "mesh": n, "sources_per_gpu": a.sources, "batch": a.batch, "coverage": coverage,
+                       "parallelism": f"sources over {world} GPU(s), all-reduce of rate grids, replicated chemistry"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_rates",
+                         "note": "136 B per cell.source (SURVEY 8d) x cells x sources of one launch / mean launch "
+                                 "time (HIP events on the library stream)"},
+            "kernel_ms_per_step": {"column_sweep": sweep_ms / a.steps, "rates": rates_ms / a.steps,
+                                   "chemistry": chem_ms / a.steps},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg)
+        print(json.dumps(out))
+    if comm is not None:
+        comm.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""ctypes binding of include/c2ray_hip.h (the C ABI a Fortran host binds with iso_c_binding).
+
+There is no CPU path: if the shared library is missing or no HIP device is present the calls
+raise; nothing here falls back to another implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+from . import _build
+
+NFREQ, NHEAT, NTAU, NCOOL = 47, 113, 2000, 801
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+
+
+class C2RayHipError(RuntimeError):
+    pass
+
+
+class Timing(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("rates_ms", C.c_double), ("chem_ms", C.c_double),
+                ("sweep_launches", C.c_int), ("rates_launches", C.c_int), ("chem_launches", C.c_int),
+                ("cells_swept", C.c_longlong)]
+
+
+# every symbol include/c2ray_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "c2r_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _ip]),
+    "c2r_destroy": (None, [C.c_void_p]),
+    "c2r_last_error": (C.c_char_p, [C.c_void_p]),
+    "c2r_create_error": (C.c_char_p, []),
+    "c2r_set_tables": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(_dp), C.c_int]),
+    "c2r_set_cooling": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
+    "c2r_set_step": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_float, C.c_double, C.c_double, C.c_double,
+                               C.c_int, C.c_double, _dp]),
+    "c2r_set_sources": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double]),
+    "c2r_upload_state": (C.c_int, [C.c_void_p, _dp, _dp, _fp]),
+    "c2r_download_state": (C.c_int, [C.c_void_p, _dp, _dp, _fp]),
+    "c2r_evolve3d": (C.c_int, [C.c_void_p, C.c_double, _ip, _ip, C.c_int]),
+    "c2r_begin_step": (C.c_int, [C.c_void_p]),
+    "c2r_set_rates_to_zero": (C.c_int, [C.c_void_p]),
+    "c2r_pass_sources": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "c2r_global_pass": (C.c_int, [C.c_void_p, C.c_double, _ip]),
+    "c2r_end_step": (C.c_int, [C.c_void_p]),
+    "c2r_download_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
+    "c2r_download_iter_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "c2r_download_columns": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "c2r_upload_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "c2r_upload_iter_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "c2r_rates_count": (C.c_size_t, [C.c_void_p]),
+    "c2r_rates_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "c2r_set_rates_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "c2r_synchronize": (C.c_int, [C.c_void_p]),
+    "c2r_set_batch": (C.c_int, [C.c_void_p, C.c_int]),
+    "c2r_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "c2r_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def library_path() -> Path:
+    return _build.LIB
+
+
+def load():
+    """Load libc2ray_hip.so (building it first if the sources are newer). Raises if that fails."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    if not path.exists():
+        raise C2RayHipError(f"{path} is missing and could not be built: the HIP extension is required")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,666 @@
+// Per-cell physics of the C2-Ray hot path as device functions for gfx950.
+//
+// Everything here is fp64 and is written so that, with -ffp-contract=off, each function
+// performs the same IEEE operations in the same order as the routine it replaces (cited
+// per function, paths relative to the reference's code/ directory).  The numerics rule
+// of the reference matters: Fortran literals without _dp are REAL(4) and dp parameters
+// initialised from them carry the float-rounded value; C2R_F(x) reproduces that.
+//
+// The file is also compilable by a host C++ compiler (C2R_HD expands to nothing) so that
+// tests/ can run the very same functions on the CPU against the golden vectors; the
+// product library never does that.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define C2R_HD __host__ __device__ __forceinline__
+#else
+#define C2R_HD inline
+#endif
+
+// Transcendental functions: by default the bit-exact restatement of the libm the reference links
+// (csrc/c2ray_math.hpp); -DC2R_USE_PLATFORM_LIBM selects the platform's exp/log10/pow instead
+// (ocml on the device), which differ from the reference's in the last bit in 1-23 % of calls.
+#if !defined(C2R_USE_PLATFORM_LIBM)
+#include "c2ray_math.hpp"
+#else
+#define C2R_MATH_EXP(x) exp(x)
+#define C2R_MATH_LOG10(x) log10(x)
+#define C2R_MATH_POW(x, y) pow(x, y)
+#endif
+
+#define C2R_F(x) ((double)(x##f))
+
+namespace c2r {
+
+constexpr int NFREQ = 47;    // radiation_sizes.f90:22
+constexpr int NHEAT = 113;   // radiation_sizes.f90:23
+constexpr int NTAU = 2000;   // radiation_sizes.f90:18
+constexpr int NTAUP = 2002;  // device column pitch: rows 0..2000 plus one duplicate of row 2000
+constexpr int NCOOL = 801;   // cooling_h.f90:25
+constexpr int NB1 = 1, NB2 = 26, NB3 = 20;
+constexpr int SUBBOXSIZE = 10;   // c2ray_parameters.f90:51
+constexpr int MAX_SUBBOX = 1150; // c2ray_parameters.f90:56
+
+// mathconstants.f90:21, abundances.f90:23-29
+constexpr double pi = C2R_F(3.141592654);
+constexpr double abu_he = C2R_F(0.074);
+constexpr double abu_c = C2R_F(7.1e-7);
+// cgsconstants.f90:26-103
+constexpr double hplanck = 6.6260755e-27;
+constexpr double k_B = 1.381e-16;
+constexpr double eth0 = C2R_F(13.598);
+constexpr double ethe0 = C2R_F(24.587);
+constexpr double ethe1 = C2R_F(54.416);
+constexpr double ev2fr = C2R_F(0.241838e15);
+constexpr double ev2k = (double)(1.0f / 8.617e-05f);
+constexpr double temph0 = eth0 * ev2k;
+constexpr double temphe0 = ethe0 * ev2k;
+constexpr double temphe1 = ethe1 * ev2k;
+constexpr double colh0 = C2R_F(1.3e-8) * C2R_F(0.83) * C2R_F(1.0) / (eth0 * eth0);
+constexpr double colhe0 = C2R_F(1.3e-8) * C2R_F(0.63) * C2R_F(2.0) / (ethe0 * ethe0);
+constexpr double colhe1 = C2R_F(1.3e-8) * C2R_F(1.30) * C2R_F(1.0) / (ethe1 * ethe1);
+constexpr double gamma1 = 5.0 / 3.0 - 1.0;
+constexpr double ion_freq_HI = ev2fr * eth0;
+constexpr double ion_freq_HeI = ev2fr * ethe0;
+// c2ray_parameters.f90:26-89
+constexpr double epsilon = 1.0e-20;
+constexpr double convergence_fraction = C2R_F(2.5e-4);
+constexpr double minimum_fractional_change = C2R_F(1.0e-2);
+constexpr double minimum_fraction_of_atoms = C2R_F(1.0e-8);
+constexpr double minitemp = C2R_F(1.0);
+constexpr double relative_denergy = C2R_F(0.1);
+// cgsphotoconstants.f90:25-50
+constexpr double sigma_HI_at_ion_freq = C2R_F(6.346e-18);
+constexpr double sigma_HeI_at_ion_freq = C2R_F(7.430e-18);
+constexpr double sigma_HeII_at_ion_freq = C2R_F(1.589e-18);
+constexpr double sigma_H_heth = 1.238e-18;
+constexpr double sigma_H_heLya = 9.907e-22;
+constexpr double sigma_He_heLya = 1.301e-20;
+constexpr double sigma_He_he2 = 1.690780687052975e-18;
+constexpr double sigma_H_he2 = 1.230695924714239e-19;
+// radiation_tables.f90:59-61
+constexpr double minlogtau = -20.0;
+constexpr double dlogtau = (4.0 - (-20.0)) / (double)(float)NTAU;
+// evolve_point.F90:91, radiation_photoionrates.f90:342,482
+constexpr double max_coldensh = C2R_F(2e29);
+constexpr double tau_photo_limit = C2R_F(1.0e-7);
+constexpr double tau_heat_limit = C2R_F(1.0e-4);
+
+// module-global recombination / collisional coefficients (cgsconstants.f90:106-133)
+struct RecCoef {
+  double arech0, brech0, areche0, breche0, oreche0, areche1, breche1, treche1;
+  double colli_HI, colli_HeI, colli_HeII, v;
+};
+
+// type ionstates (files_for_3D/mat_ini_test.F90:70-77)
+struct IonStates {
+  double h[2], he[3], h_av[2], he_av[3], h_old[2], he_old[3];
+};
+
+// per-band vectors and table pointers the kernels read (uniform data)
+struct BandData {
+  double sigma_HI[NFREQ], sigma_HeI[NFREQ], sigma_HeII[NFREQ];
+  // secondary ionisation fractions, index band-2 (bands 2..47); radiation_sizes.f90:198-370
+  double f1ion_HI[NFREQ - 1], f1ion_HeI[NFREQ - 1], f1ion_HeII[NFREQ - 1];
+  double f2ion_HI[NFREQ - 1], f2ion_HeI[NFREQ - 1], f2ion_HeII[NFREQ - 1];
+  double f1heat_HI[NFREQ - 1], f1heat_HeI[NFREQ - 1], f1heat_HeII[NFREQ - 1];
+  double f2heat_HI[NFREQ - 1], f2heat_HeI[NFREQ - 1], f2heat_HeII[NFREQ - 1];
+  int bb_upper;
+};
+
+C2R_HD double dmax(double a, double b) { return a > b ? a : b; }
+C2R_HD double dmin(double a, double b) { return a < b ? a : b; }
+
+// ----------------------------------------------------------------------------------------
+// cgsconstants.f90:140-266  ini_rec_colion_factors
+C2R_HD void ini_rec_colion_factors(double T, RecCoef &rc) {
+  double lambda = 2.0 * (temph0 / T);
+  rc.arech0 = C2R_F(1.269e-13) * C2R_MATH_POW(lambda, 1.503) /
+              C2R_MATH_POW(1.0 + C2R_MATH_POW(lambda / C2R_F(0.522), C2R_F(0.470)), C2R_F(1.923));
+  rc.brech0 = C2R_F(2.753e-14) * C2R_MATH_POW(lambda, 1.500) /
+              C2R_MATH_POW(1.0 + C2R_MATH_POW(lambda / C2R_F(2.740), C2R_F(0.407)), C2R_F(2.242));
+  if (T < 9.e3) {
+    lambda = 2.0 * (temph0 / T);
+    rc.areche0 = 1.269e-13 * C2R_MATH_POW(lambda, 1.503) /
+                 C2R_MATH_POW(1.0 + C2R_MATH_POW(lambda / C2R_F(0.522), C2R_F(0.470)), C2R_F(1.923));
+    rc.breche0 = 2.753e-14 * C2R_MATH_POW(lambda, 1.500) /
+                 C2R_MATH_POW(1.0 + C2R_MATH_POW(lambda / C2R_F(2.740), C2R_F(0.407)), C2R_F(2.242));
+  } else {
+    lambda = 2.0 * (temphe0 / T);
+    double dielectronic =
+        1.9e-3 * C2R_MATH_POW(T, -1.5) * C2R_MATH_EXP(-4.7e5 / T) * (1.0 + 0.3 * C2R_MATH_EXP(-9.4e4 / T));
+    rc.areche0 = 3.000e-14 * C2R_MATH_POW(lambda, 0.654) + dielectronic;
+    // the flang -O2 build of the reference evaluates x**0.750 as sqrt(x)*sqrt(sqrt(x))
+    rc.breche0 = 1.260e-14 * (sqrt(lambda) * sqrt(sqrt(lambda))) + dielectronic;
+  }
+  rc.oreche0 = rc.areche0 - rc.breche0;
+  lambda = 2.0 * (temphe1 / T);
+  rc.breche1 = 5.5060e-14 * C2R_MATH_POW(lambda, 1.5) /
+               C2R_MATH_POW(1.0 + C2R_MATH_POW(lambda / 2.740, 0.407), 2.242);
+  rc.areche1 = C2R_F(2.538e-13) * C2R_MATH_POW(lambda, 1.503) /
+               C2R_MATH_POW(1.0 + C2R_MATH_POW(lambda / 0.522, 0.470), 1.923);
+  rc.treche1 = 3.4e-13 * C2R_MATH_POW(T / 1.0e4, -0.6);
+  rc.v = 0.285 * C2R_MATH_POW(T / 1.0e4, 0.119);
+  double sqrtt0 = sqrt(T);
+  rc.colli_HI = colh0 * sqrtt0 * C2R_MATH_EXP(-temph0 / T);
+  rc.colli_HeI = colhe0 * sqrtt0 * C2R_MATH_EXP(-temphe0 / T);
+  rc.colli_HeII = colhe1 * sqrtt0 * C2R_MATH_EXP(-temphe1 / T);
+}
+
+// tped.f90:41-84
+C2R_HD double temper2pressr(double temper, double ndens, double eldens) { return (ndens + eldens) * k_B * temper; }
+C2R_HD double pressr2temper(double pressr, double ndens, double eldens) { return pressr / (k_B * (ndens + eldens)); }
+C2R_HD double electrondens(double ndens, const double *xh, const double *xhe) {
+  return ndens * (xh[1] * (1.0 - abu_he) + abu_c + abu_he * (xhe[1] + 2.0 * xhe[2]));
+}
+// doric.f90:358-372
+C2R_HD double coldens(double path, double neufrac, double ndens, double abundance) {
+  return neufrac * ndens * path * abundance;
+}
+
+// doric.f90:317-351
+C2R_HD void prepare_doric_factors(double NH, double NHe0, double NHe1, double &yfrac, double &zfrac,
+                                  double &y2afrac, double &y2bfrac) {
+  double tau_H_heth = NH * sigma_H_heth;
+  double tau_He_heth = NHe0 * sigma_HeI_at_ion_freq;
+  double tau_H_heLya = NH * sigma_H_heLya;
+  double tau_He_heLya = NHe0 * sigma_He_heLya;
+  double tau_H_he2th = NH * sigma_H_he2;
+  double tau_He_he2th = NHe0 * sigma_He_he2;
+  double tau_He2_he2th = NHe1 * sigma_HeII_at_ion_freq;
+  yfrac = tau_H_heth / (tau_H_heth + tau_He_heth);
+  zfrac = tau_H_heLya / (tau_H_heLya + tau_He_heLya);
+  y2afrac = tau_He2_he2th / (tau_He2_he2th + tau_He_he2th + tau_H_he2th);
+  y2bfrac = tau_He_he2th / (tau_He2_he2th + tau_He_he2th + tau_H_he2th);
+}
+
+// doric.f90:35-313
+C2R_HD void doric(double dt, double rhe, IonStates &ion, double phi_HI, double phi_HeI, double phi_HeII,
+                  double yfrac, double zfrac, double y2afrac, double y2bfrac, const RecCoef &rc,
+                  double clumping) {
+  const double v = rc.v;
+  const double pfrac = 0.96;
+  const double heliumfraction = abu_he / (1.0 - abu_he);
+  double ffrac = dmax(dmin(10.0 * ion.h[0], 1.0), 0.01);
+  double wfrac = (1.425 - 0.737) + 0.737 * yfrac;
+
+  double alpha_h_B = clumping * rc.brech0;
+  double alpha_he_1 = clumping * rc.oreche0;
+  double alpha_he_B = clumping * rc.breche0;
+  double alpha_he_A = clumping * rc.areche0;
+  double alpha_he2_B = clumping * rc.breche1;
+  double alpha_he2_A = clumping * rc.areche1;
+  double alpha_he2_2 = clumping * rc.treche1;
+  double alpha_he2_1 = alpha_he2_A - alpha_he2_B;
+
+  double aih0 = dmax(phi_HI + rhe * rc.colli_HI, 1.0e-200);
+  double aihe0 = dmax(phi_HeI + rhe * rc.colli_HeI, 1.0e-200);
+  double aihe1 = dmax(phi_HeII + rhe * rc.colli_HeII, 1.0e-200);
+
+  double Lmat = -(aih0 + rhe * alpha_h_B);
+  double Mmat = (yfrac * rhe * alpha_he_1 + pfrac * rhe * alpha_he_B) * heliumfraction;
+  double Nmat = ((ffrac * zfrac * (1.0 - v) + v * wfrac) * alpha_he2_B + alpha_he2_2 +
+                 (1.0 - y2afrac - y2bfrac) * alpha_he2_1) * heliumfraction * rhe;
+  double Pmat = -aihe0 - aihe1 - rhe * (alpha_he_A - (1.0 - yfrac) * alpha_he_1);
+  double Emat = -rhe * (alpha_he2_A - y2afrac * alpha_he2_1);
+  double Qmat = -aihe0 + rhe * alpha_he2_B * (ffrac * (1.0 - zfrac) * (1.0 - v) + v * (1.425 - wfrac)) -
+                Emat + alpha_he2_1 * y2bfrac * rhe;
+
+  double Bcoef = Emat - Pmat;
+  double Scoef = sqrt(Bcoef * Bcoef + 4.0 * aihe1 * Qmat);
+  double QHEPcoef = 1.0 / (Qmat * aihe1 - Emat * Pmat);
+  double BminusS = Bcoef - Scoef;
+  double BplusS = Bcoef + Scoef;
+
+  double lambda1 = Lmat;
+  double lambda2 = 0.5 * (Emat + Pmat - Scoef);
+  double lambda3 = 0.5 * (Emat + Pmat + Scoef);
+
+  double rx = -1.0 / Lmat * (aih0 + (Mmat * Emat - Nmat * aihe1) * (aihe0 * QHEPcoef));
+  double ry = aihe0 * (Emat * QHEPcoef);
+  double rz = -aihe0 * (aihe1 * QHEPcoef);
+
+  double twoaihe1 = 2.0 * aihe1;
+  double eigv2x = -Nmat / (Lmat - lambda2) + (Mmat / twoaihe1) * BplusS / (Lmat - lambda2);
+  double eigv3x = (-twoaihe1 * Nmat + Mmat * (BminusS)) / (twoaihe1 * (Lmat - lambda3));
+  double eigv2y = (-BplusS) / (twoaihe1);
+  double eigv3y = (-BminusS) / (twoaihe1);
+
+  double Rcoef = twoaihe1 * (ry - ion.he_old[1]);
+  double Tcoef = rz - ion.he_old[2];
+
+  double coef2 = (Rcoef + (BminusS)*Tcoef) / (2.0 * Scoef);
+  double coef3 = -(Rcoef + (BplusS)*Tcoef) / (2.0 * Scoef);
+  double coef1 = -rx + (eigv3x - eigv2x) * (Rcoef / (2.0 * Scoef)) +
+                 Tcoef * ((BplusS * eigv3x / (2.0 * Scoef) - BminusS * eigv2x / (2.0 * Scoef))) +
+                 ion.h_old[1];
+
+  double lam1dt = dt * lambda1, lam2dt = dt * lambda2, lam3dt = dt * lambda3;
+  double elam1dt = C2R_MATH_EXP(lam1dt), elam2dt = C2R_MATH_EXP(lam2dt), elam3dt = C2R_MATH_EXP(lam3dt);
+
+  ion.h[1] = coef1 * elam1dt + coef2 * elam2dt * eigv2x + coef3 * elam3dt * eigv3x + rx;
+  ion.he[1] = coef2 * elam2dt * eigv2y + coef3 * elam3dt * eigv3y + ry;
+  ion.he[2] = coef2 * elam2dt + coef3 * elam3dt + rz;
+  ion.h[0] = 1.0 - ion.h[1];
+  ion.he[0] = 1.0 - ion.he[1] - ion.he[2];
+
+  if (ion.h[0] < epsilon) { ion.h[0] = epsilon; ion.h[1] = 1.0 - epsilon; }
+  if (ion.h[1] < epsilon) { ion.h[1] = epsilon; ion.h[0] = 1.0 - epsilon; }
+  if (ion.he[0] <= epsilon || ion.he[1] <= epsilon || ion.he[2] <= epsilon) {
+    if (ion.he[0] < epsilon) ion.he[0] = epsilon;
+    if (ion.he[1] < epsilon) ion.he[1] = epsilon;
+    if (ion.he[2] < epsilon) ion.he[2] = epsilon;
+    double normfac = ion.he[0] + ion.he[1] + ion.he[2];
+    ion.he[0] = ion.he[0] / normfac;
+    ion.he[1] = ion.he[1] / normfac;
+    ion.he[2] = ion.he[2] / normfac;
+  }
+
+  const double small = C2R_F(1.0e-8);
+  double avg_factor_1, avg_factor_2, avg_factor_3;
+  if (fabs(lam1dt) < small) avg_factor_1 = coef1; else avg_factor_1 = coef1 * (elam1dt - 1.0) / lam1dt;
+  if (fabs(lam2dt) < small) avg_factor_2 = coef2; else avg_factor_2 = coef2 * (elam2dt - 1.0) / lam2dt;
+  if (fabs(lam3dt) < small) avg_factor_3 = coef3; else avg_factor_3 = coef3 * (elam3dt - 1.0) / lam3dt;
+
+  ion.h_av[1] = rx + avg_factor_1 + eigv2x * avg_factor_2 + eigv3x * avg_factor_3;
+  ion.he_av[1] = ry + eigv2y * avg_factor_2 + eigv3y * avg_factor_3;
+  ion.he_av[2] = rz + avg_factor_2 + avg_factor_3;
+  ion.h_av[0] = 1.0 - ion.h_av[1];
+  ion.he_av[0] = 1.0 - ion.he_av[1] - ion.he_av[2];
+
+  if (ion.h_av[1] < epsilon) { ion.h_av[1] = epsilon; ion.h_av[0] = 1.0 - epsilon; }
+  if (ion.h_av[0] < epsilon) { ion.h_av[0] = epsilon; ion.h_av[1] = 1.0 - epsilon; }
+  if (ion.he_av[0] <= epsilon || ion.he_av[1] <= epsilon || ion.he_av[2] <= epsilon) {
+    if (ion.he_av[1] < epsilon) ion.he_av[1] = epsilon;
+    if (ion.he_av[2] < epsilon) ion.he_av[2] = epsilon;
+    if (ion.he_av[0] < epsilon) ion.he_av[0] = epsilon;
+    double normfac = ion.he_av[0] + ion.he_av[1] + ion.he_av[2];
+    ion.he_av[0] = ion.he_av[0] / normfac;
+    ion.he_av[1] = ion.he_av[1] / normfac;
+    ion.he_av[2] = ion.he_av[2] / normfac;
+  }
+}
+
+// cooling_h.f90:40-71; cool = 5 x 801 linear curves (h0, h1, he0, he1, he2)
+C2R_HD double coolin(const double *cool, double mintemp, double dtemp, double nucldens, double eldens,
+                     const double *xh, const double *xhe, double temp0) {
+  double tpos = (C2R_MATH_LOG10(temp0) - mintemp) / dtemp + 1.0;
+  int itpos = (int)tpos;
+  itpos = itpos < 1 ? 1 : itpos;
+  itpos = itpos > NCOOL - 1 ? NCOOL - 1 : itpos;
+  double dtpos = tpos - (double)itpos;
+  int itpos1 = itpos + 1 > NCOOL ? NCOOL : itpos + 1;
+  int a = itpos - 1, b = itpos1 - 1;
+  const double *h0 = cool, *h1 = cool + NCOOL, *he0 = cool + 2 * NCOOL, *he1 = cool + 3 * NCOOL,
+               *he2 = cool + 4 * NCOOL;
+  return nucldens * eldens *
+         ((xh[0] * (h0[a] + (h0[b] - h0[a]) * dtpos) + xh[1] * (h1[a] + (h1[b] - h1[a]) * dtpos)) * (1.0 - abu_he) +
+          (xhe[0] * (he0[a] + (he0[b] - he0[a]) * dtpos) + xhe[1] * (he1[a] + (he1[b] - he1[a]) * dtpos) +
+           xhe[2] * (he2[a] + (he2[b] - he2[a]) * dtpos)) * abu_he);
+}
+
+// cosmology.f90:207-234
+C2R_HD double cosmo_cool(double e_int, double zred, double H0, double Omega0) {
+  double opz = 1.0 + zred;
+  double dzdt = H0 * opz * sqrt(Omega0 * (opz * opz * opz) + 1.0 - Omega0);
+  return e_int * 2.0 / (1.0 + zred) * dzdt;
+}
+
+struct CoolData {
+  const double *cool;
+  double mintemp, dtemp;
+  double zred, H0, Omega0;
+};
+
+// thermal.f90:22-174 (cosmological = .true.)
+C2R_HD void thermal(const CoolData &cd, double dt, double &end_temper, double &avg_temper, double ndens_electron,
+                    double ndens_atom, const IonStates &ion, double heating) {
+  double internal_energy =
+      temper2pressr(end_temper, ndens_atom, electrondens(ndens_atom, ion.h_old, ion.he_old)) / gamma1;
+  double cosmo_cool_rate = cosmo_cool(internal_energy, cd.zred, cd.H0, cd.Omega0);
+  if (end_temper > minitemp) {
+    double cumulative_time = 0.0;
+    int i_heating = 0;
+    avg_temper = 0.0;
+    double initial_temp = end_temper;
+    const double eldens_av = electrondens(ndens_atom, ion.h_av, ion.he_av);
+    for (;;) {
+      i_heating++;
+      double cooling =
+          coolin(cd.cool, cd.mintemp, cd.dtemp, ndens_atom, ndens_electron, ion.h_av, ion.he_av, end_temper) +
+          cosmo_cool_rate;
+      double thermal_rate = dmax(1e-50, fabs(cooling - heating));
+      double thermal_timescale = internal_energy / fabs(thermal_rate);
+      double dt_thermal = relative_denergy * thermal_timescale;
+      double dt_ODE = dmin(dt_thermal, dt - cumulative_time);
+      internal_energy = internal_energy + dt_ODE * (heating - cooling);
+      avg_temper = avg_temper + 0.5 * end_temper * dt_ODE;
+      end_temper = pressr2temper(internal_energy * gamma1, ndens_atom, eldens_av);
+      avg_temper = avg_temper + 0.5 * end_temper * dt_ODE;
+      if (end_temper < minitemp) {
+        internal_energy = temper2pressr(minitemp, ndens_atom, eldens_av); // thermal.f90:141, no /gamma1
+        end_temper = minitemp;
+      }
+      cumulative_time = cumulative_time + dt_ODE;
+      if (cumulative_time >= dt || fabs(cumulative_time - dt) < C2R_F(1e-6) * dt) break;
+      if (i_heating > 10000) break;
+    }
+    if (dt > 0.0) avg_temper = avg_temper / dt; else avg_temper = initial_temp;
+    end_temper = pressr2temper(internal_energy * gamma1, ndens_atom, electrondens(ndens_atom, ion.h, ion.he));
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// radiation_photoionrates.f90: table position of one optical depth (:282-306)
+struct TauPos {
+  int ipos;
+  double residual;
+};
+C2R_HD TauPos tau_table_position(double tau) {
+  double lt = C2R_MATH_LOG10(dmax(1.0e-20, tau));
+  double odpos = dmin((double)NTAU, dmax(0.0, 1.0 + (lt - minlogtau) / dlogtau));
+  TauPos p;
+  p.ipos = (int)odpos;
+  p.residual = odpos - (double)p.ipos;
+  return p;
+}
+// :310-326; col points at row 0 of a column with pitch NTAUP whose row 2001 duplicates row 2000,
+// so that ipos_p1 = min(NumTau, ipos+1) needs no clamp: (c[2001]-c[2000])*residual == 0 exactly.
+C2R_HD double read_table(const double *col, const TauPos &p) {
+  double a = col[p.ipos], b = col[p.ipos + 1];
+  return a + (b - a) * p.residual;
+}
+
+struct PhotoOut {
+  double photo_HI, photo_HeI, photo_HeII; // cell rates (before division by neutral densities)
+  double heat;
+  double photo_out;                       // photons leaving the cell (all bands)
+};
+
+// radiation_photoionrates.f90:108-277 photoion_rates with its callees photo_lookuptable (:331-464),
+// heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands.
+// Band-local quantities are computed in the reference's order; sums over bands run b = 1..bb_upper
+// as in the reference.  HEAT selects the non-isothermal path.
+template <bool HEAT>
+C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
+                           const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
+                           double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
+                           double NFlux, double i_state, PhotoOut &o) {
+  o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
+  o.heat = 0.0;
+  o.photo_out = 0.0;
+  if (!(NFlux > 0.0)) return;
+  const double cell_HI = cout_HI - cin_HI;
+  const double cell_HeI = cout_HeI - cin_HeI;
+  const double cell_HeII = cout_HeII - cin_HeII;
+
+  double f_heat = 0.0, f_ion_HI = 0.0, f_ion_HeI = 0.0;
+  double df_ion_HI = 0.0, df_ion_HeI = 0.0;
+  double y1R[3], y2R[3];
+  if (HEAT) {
+    // Ricotti et al. 2002 secondary ionisation parameters (:49-55, :558-564)
+    const double CR1[3] = {0.3908, 0.0554, 1.0}, bR1[3] = {0.4092, 0.4614, 0.2663},
+                 dR1[3] = {1.7592, 1.6660, 1.3163};
+    const double CR2[3] = {0.6941, 0.0984, 3.9811}, aR2[3] = {0.2, 0.2, 0.4}, bR2[3] = {0.38, 0.38, 0.34};
+    for (int i = 0; i < 3; i++) {
+      y1R[i] = CR1[i] * C2R_MATH_POW(1.0 - C2R_MATH_POW(i_state, bR1[i]), dR1[i]);
+      double xeb = 1.0 - C2R_MATH_POW(i_state, bR2[i]);
+      y2R[i] = CR2[i] * C2R_MATH_POW(i_state, aR2[i]) * xeb * xeb;
+    }
+  }
+
+  const int nb = bd.bb_upper;
+  for (int b = 0; b < nb; b++) { // b is 0-based here; reference band = b+1
+    const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
+    const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+    const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
+    const TauPos pin = tau_table_position(tau_in);
+    const double dtau = tau_out - tau_in;
+    const bool thick = fabs(dtau) > tau_photo_limit;
+    const bool hthick = fabs(dtau) > tau_heat_limit;
+    TauPos pout;
+    if (thick || (HEAT && hthick)) pout = tau_table_position(tau_out);
+    else { pout.ipos = 0; pout.residual = 0.0; }
+
+    // species split of this band (scale_int2 / scale_int3)
+    double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
+    if (b >= NB1 && b < NB1 + NB2) {
+      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI);
+      sc_HI = sHI * cell_HI * forscaleing;
+      sc_HeI = sHeI * cell_HeI * forscaleing;
+    } else if (b >= NB1 + NB2) {
+      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
+      sc_HI = cell_HI * sHI * forscaleing;
+      sc_HeI = cell_HeI * sHeI * forscaleing;
+      sc_HeII = cell_HeII * sHeII * forscaleing;
+    }
+
+    // photo_lookuptable body
+    {
+      const double *tk = photo_thick + (size_t)b * NTAUP;
+      double phi_in = NFlux * read_table(tk, pin);
+      double phi_out, phi_all;
+      if (thick) {
+        phi_out = NFlux * read_table(tk, pout);
+        phi_all = phi_in - phi_out;
+      } else {
+        phi_all = NFlux * dtau * read_table(photo_thin + (size_t)b * NTAUP, pin);
+        phi_out = phi_in - phi_all;
+      }
+      o.photo_out = o.photo_out + phi_out;
+      if (b < NB1) {
+        o.photo_HI = o.photo_HI + phi_all / vol;
+      } else if (b < NB1 + NB2) {
+        o.photo_HI = o.photo_HI + sc_HI * phi_all / vol;
+        o.photo_HeI = o.photo_HeI + sc_HeI * phi_all / vol;
+      } else {
+        o.photo_HI = o.photo_HI + sc_HI * phi_all / vol;
+        o.photo_HeI = o.photo_HeI + sc_HeI * phi_all / vol;
+        o.photo_HeII = o.photo_HeII + sc_HeII * phi_all / vol;
+      }
+    }
+
+    if (HEAT) {
+      double df_heat;
+      if (b < NB1) {
+        const double *tk = heat_thick + (size_t)b * NTAUP;
+        double in_HI = NFlux * read_table(tk, pin);
+        double h_HI;
+        if (hthick) {
+          double out_HI = NFlux * read_table(tk, pout);
+          h_HI = (in_HI - out_HI) / vol;
+        } else {
+          h_HI = NFlux * (cell_HI * sHI) * read_table(heat_thin + (size_t)b * NTAUP, pin);
+          h_HI = h_HI / vol;
+        }
+        df_heat = h_HI;
+      } else if (b < NB1 + NB2) {
+        const int cH = 2 * (b + 1) - NB1 - 1 - 1; // 0-based heating column of (band, HI)
+        const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP;
+        double in_HI = NFlux * read_table(tkH, pin);
+        double in_HeI = NFlux * read_table(tkHe, pin);
+        double h_HI, h_HeI;
+        if (hthick) {
+          double out_HI = NFlux * read_table(tkH, pout);
+          h_HI = sc_HI * (in_HI - out_HI) / vol;
+          double out_HeI = NFlux * read_table(tkHe, pout);
+          h_HeI = sc_HeI * (in_HeI - out_HeI) / vol;
+        } else {
+          const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
+          h_HI = NFlux * (cell_HI * sHI) * read_table(tnH, pin);
+          h_HI = h_HI / vol;
+          h_HeI = NFlux * (cell_HeI * sHeI) * read_table(tnHe, pin);
+          h_HeI = h_HeI / vol;
+        }
+        df_heat = h_HI + h_HeI;
+        const int q = b - 1; // f arrays are dimension(2:47)
+        double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI;
+        double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
+        double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
+        double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
+        df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
+        df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
+        df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+      } else {
+        const int cH = 3 * (b + 1) - NB2 - NB1 * 2 - 2 - 1;
+        const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP, *tkHe2 = tkHe + NTAUP;
+        double in_HI = NFlux * read_table(tkH, pin);
+        double in_HeI = NFlux * read_table(tkHe, pin);
+        double in_HeII = NFlux * read_table(tkHe2, pin);
+        double h_HI, h_HeI, h_HeII;
+        if (hthick) {
+          double out_HI = NFlux * read_table(tkH, pout);
+          h_HI = sc_HI * (in_HI - out_HI) / vol;
+          double out_HeI = NFlux * read_table(tkHe, pout);
+          h_HeI = sc_HeI * (in_HeI - out_HeI) / vol;
+          double out_HeII = NFlux * read_table(tkHe2, pout);
+          h_HeII = sc_HeII * (in_HeII - out_HeII) / vol;
+        } else {
+          const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
+          h_HI = NFlux * (cell_HI * sHI) * read_table(tnH, pin);
+          h_HI = h_HI / vol;
+          h_HeI = NFlux * (cell_HeI * sHeI) * read_table(tnHe, pin);
+          h_HeI = h_HeI / vol;
+          h_HeII = NFlux * (cell_HeII * sHeII) * read_table(tnHe2, pin);
+          h_HeII = h_HeII / vol;
+        }
+        df_heat = h_HI + h_HeI + h_HeII;
+        const int q = b - 1;
+        double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI + bd.f1ion_HeII[q] * h_HeII;
+        double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
+        double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
+        double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
+        df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
+        df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
+        df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+      }
+      f_heat = f_heat + df_heat;
+      f_ion_HI = f_ion_HI + df_ion_HI;
+      f_ion_HeI = f_ion_HeI + df_ion_HeI;
+    }
+  }
+  if (HEAT) {
+    // phi = phi + heat_lookuptable(...) (:247-252): adds to photo_cell_HI / HeI and heat
+    o.heat = f_heat;
+    o.photo_HI = o.photo_HI + f_ion_HI / (ion_freq_HI * hplanck);
+    o.photo_HeI = o.photo_HeI + f_ion_HeI / (ion_freq_HeI * hplanck);
+  }
+}
+
+// photo_out only (the quantity evolve0D adds to the photon loss of boundary cells,
+// evolve_point.F90:310-315): same band loop as photo_lookuptable, nothing else.
+C2R_HD double photo_out_only(const BandData &bd, const double *photo_thick, const double *photo_thin,
+                             double cin_HI, double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII,
+                             double cout_HeII, double NFlux) {
+  double photo_out = 0.0;
+  if (!(NFlux > 0.0)) return photo_out;
+  const int nb = bd.bb_upper;
+  for (int b = 0; b < nb; b++) {
+    const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
+    const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+    const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
+    const TauPos pin = tau_table_position(tau_in);
+    const double *tk = photo_thick + (size_t)b * NTAUP;
+    double phi_in = NFlux * read_table(tk, pin);
+    double phi_out;
+    if (fabs(tau_out - tau_in) > tau_photo_limit) {
+      const TauPos pout = tau_table_position(tau_out);
+      phi_out = NFlux * read_table(tk, pout);
+    } else {
+      double phi_all = NFlux * (tau_out - tau_in) * read_table(photo_thin + (size_t)b * NTAUP, pin);
+      phi_out = phi_in - phi_all;
+    }
+    photo_out = photo_out + phi_out;
+  }
+  return photo_out;
+}
+
+// ----------------------------------------------------------------------------------------
+// files_for_3D/column_density.f90:28-376 -- geometry part of cinterp: which four upstream cells,
+// their bilinear weights, the diagonal factor and the path length (in cell units) for the
+// unwrapped offset (idel,jdel,kdel) = rtpos - srcpos of a source at mesh position (i0,j0,k0).
+// The crossing point is formed in ABSOLUTE mesh coordinates as the reference does
+// (xc = alam*di + real(i0), :113): the rounding of that sum depends on i0, so the weights do too.
+struct ShortChar {
+  int ci[4], cj[4], ck[4]; // unwrapped offsets (relative to the source) of the four corners c1..c4
+  double s[4];             // s1..s4
+  double diag;             // 1, sqrt2 or sqrt3 (single-precision values, :53-54)
+  double path;
+};
+C2R_HD int isign1(int x) { return x >= 0 ? 1 : -1; } // sign(1,x)
+
+C2R_HD void short_characteristic(int i0, int j0, int k0, int idel, int jdel, int kdel, ShortChar &sc) {
+  const double sqrt3 = 1.73205077648162842, sqrt2 = 1.41421353816986084; // (double)sqrtf(3), (double)sqrtf(2)
+  const int idela = idel < 0 ? -idel : idel, jdela = jdel < 0 ? -jdel : jdel, kdela = kdel < 0 ? -kdel : kdel;
+  const int sgni = isign1(idel), sgnj = isign1(jdel), sgnk = isign1(kdel);
+  const int im = idel - sgni, jm = jdel - sgnj, km = kdel - sgnk; // offsets of the cell closer to the source
+  const double di = (double)idel, dj = (double)jdel, dk = (double)kdel;
+  bool d2, d3;
+  if (kdela >= jdela && kdela >= idela) { // :107 z-plane crossing
+    double alam = ((double)km + sgnk * 0.5) / dk;
+    double xc = alam * di + (double)i0, yc = alam * dj + (double)j0;
+    double dx = 2.0 * fabs(xc - ((double)(i0 + im) + 0.5 * sgni));
+    double dy = 2.0 * fabs(yc - ((double)(j0 + jm) + 0.5 * sgnj));
+    sc.s[0] = (1. - dx) * (1. - dy);
+    sc.s[1] = (1. - dy) * dx;
+    sc.s[2] = (1. - dx) * dy;
+    sc.s[3] = dx * dy;
+    sc.ci[0] = im;   sc.cj[0] = jm;   sc.ck[0] = km;
+    sc.ci[1] = idel; sc.cj[1] = jm;   sc.ck[1] = km;
+    sc.ci[2] = im;   sc.cj[2] = jdel; sc.ck[2] = km;
+    sc.ci[3] = idel; sc.cj[3] = jdel; sc.ck[3] = km;
+    d2 = (kdela == 1 && (idela == 1 || jdela == 1));
+    d3 = (idela == 1 && jdela == 1);
+    sc.path = sqrt((di * di + dj * dj) / (dk * dk) + 1.0);
+  } else if (jdela >= idela && jdela >= kdela) { // :199 y-plane crossing
+    double alam = ((double)jm + sgnj * 0.5) / dj;
+    double zc = alam * dk + (double)k0, xc = alam * di + (double)i0;
+    double dz = 2.0 * fabs(zc - ((double)(k0 + km) + 0.5 * sgnk));
+    double dx = 2.0 * fabs(xc - ((double)(i0 + im) + 0.5 * sgni));
+    sc.s[0] = (1. - dx) * (1. - dz);
+    sc.s[1] = (1. - dz) * dx;
+    sc.s[2] = (1. - dx) * dz;
+    sc.s[3] = dx * dz;
+    sc.ci[0] = im;   sc.cj[0] = jm; sc.ck[0] = km;
+    sc.ci[1] = idel; sc.cj[1] = jm; sc.ck[1] = km;
+    sc.ci[2] = im;   sc.cj[2] = jm; sc.ck[2] = kdel;
+    sc.ci[3] = idel; sc.cj[3] = jm; sc.ck[3] = kdel;
+    d2 = (jdela == 1 && (idela == 1 || kdela == 1));
+    d3 = (idela == 1 && kdela == 1);
+    sc.path = sqrt((di * di + dk * dk) / (dj * dj) + 1.0);
+  } else { // :275 x-plane crossing
+    double alam = ((double)im + sgni * 0.5) / di;
+    double zc = alam * dk + (double)k0, yc = alam * dj + (double)j0;
+    double dz = 2.0 * fabs(zc - ((double)(k0 + km) + 0.5 * sgnk));
+    double dy = 2.0 * fabs(yc - ((double)(j0 + jm) + 0.5 * sgnj));
+    sc.s[0] = (1. - dz) * (1. - dy);
+    sc.s[1] = (1. - dz) * dy;
+    sc.s[2] = (1. - dy) * dz;
+    sc.s[3] = dy * dz;
+    sc.ci[0] = im; sc.cj[0] = jm;   sc.ck[0] = km;
+    sc.ci[1] = im; sc.cj[1] = jdel; sc.ck[1] = km;
+    sc.ci[2] = im; sc.cj[2] = jm;   sc.ck[2] = kdel;
+    sc.ci[3] = im; sc.cj[3] = jdel; sc.ck[3] = kdel;
+    d2 = (idela == 1 && (jdela == 1 || kdela == 1));
+    d3 = (jdela == 1 && kdela == 1);
+    sc.path = sqrt(1.0 + (dj * dj + dk * dk) / (di * di));
+  }
+  sc.diag = d2 ? (d3 ? sqrt3 : sqrt2) : 1.0;
+}
+
+// column_density.f90:351-376 weightf
+C2R_HD double weightf(double cd, double sig) { return 1.0 / dmax(0.6, cd * sig); }
+
+// weighted mean of the four corner columns of one species (:145-163) times the diagonal factor
+C2R_HD double interp_column(const ShortChar &sc, double c1, double c2, double c3, double c4, double sig) {
+  double w1 = sc.s[0] * weightf(c1, sig), w2 = sc.s[1] * weightf(c2, sig), w3 = sc.s[2] * weightf(c3, sig),
+         w4 = sc.s[3] * weightf(c4, sig);
+  double c = (c1 * w1 + c2 * w2 + c3 * w3 + c4 * w4) / (w1 + w2 + w3 + w4);
+  if (sc.diag != 1.0) c = sc.diag * c;
+  return c;
+}
+
+} // namespace c2r

@@ -1,0 +1,1022 @@
+// MI355X (gfx950) implementation of C2-Ray's evolve3D hot path behind the C ABI of
+// include/c2ray_hip.h.  See DESIGN.md for the data layout and the kernel list.
+//
+//   column sweep   k_sweep_shell   one launch per L-infinity shell around the sources of a batch:
+//                                  short-characteristics interpolation of the three incoming
+//                                  columns (cinterp) + the cell's own columns (evolve0D, first half)
+//   rates          k_rates         all cells x all sources of the batch, no dependencies:
+//                                  photoion_rates + accumulation into the rate grids in source order
+//                                  (evolve0D, second half)
+//   chemistry      k_chemistry     evolve0D_global / do_chemistry / doric / thermal per cell
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/c2ray_hip.h"
+#include "c2ray_device.hpp"
+
+using namespace c2r;
+
+namespace {
+
+constexpr int MAXB = 16;      // sources per batch of launches (kernel-argument array)
+constexpr int BLOCK = 256;
+
+struct Grid {
+  int n1, n2, n3;
+  int l1, l2, l3; // left extent mesh/2 (evolve_source.F90:105)
+  size_t ncell;
+};
+
+struct SrcInfo {
+  int i0, j0, k0;      // 1-based mesh position (srcpos)
+  int lo[3], hi[3];    // current sub-box, as offsets last_l - srcpos, last_r - srcpos
+  double nflux;        // NormFlux(ns)
+  int slot;            // scratch slot
+  int pad;
+};
+struct BatchArgs {
+  int n;
+  SrcInfo s[MAXB];
+};
+
+struct StepScalars {
+  double dr1, dr2, dr3, vol;
+  double clumping;
+  double temper_val;
+  RecCoef rc;
+  CoolData cd;
+};
+
+__device__ __forceinline__ int wrap0(int x, int n) { // 0-based periodic index of x in [-n, 2n)
+  if (x < 0) x += n;
+  else if (x >= n) x -= n;
+  return x;
+}
+__device__ __forceinline__ size_t cell_index(const Grid &g, int i0, int j0, int k0, int di, int dj, int dk) {
+  int i = wrap0(i0 - 1 + di, g.n1), j = wrap0(j0 - 1 + dj, g.n2), k = wrap0(k0 - 1 + dk, g.n3);
+  return (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+}
+
+// number of cells of the L-infinity shell s
+__host__ __device__ inline long long shell_count(int s) { return s == 0 ? 1 : 24LL * s * s + 2; }
+
+// t in [0, shell_count(s)) -> offset (di,dj,dk) with max(|di|,|dj|,|dk|) == s; i runs fastest on
+// the k- and j-faces so that consecutive lanes touch consecutive memory there.
+__device__ __forceinline__ void shell_decode(int s, int t, int &di, int &dj, int &dk) {
+  if (s == 0) { di = dj = dk = 0; return; }
+  const int w = 2 * s + 1, v = 2 * s - 1;
+  const int A = w * w, B = v * w, C = v * v;
+  if (t < 2 * A) {
+    dk = t < A ? s : -s;
+    if (t >= A) t -= A;
+    dj = t / w - s;
+    di = t % w - s;
+  } else if (t < 2 * A + 2 * B) {
+    t -= 2 * A;
+    dj = t < B ? s : -s;
+    if (t >= B) t -= B;
+    dk = t / w - (s - 1);
+    di = t % w - s;
+  } else {
+    t -= 2 * A + 2 * B;
+    di = t < C ? s : -s;
+    if (t >= C) t -= C;
+    dk = t / v - (s - 1);
+    dj = t % v - (s - 1);
+  }
+}
+
+__device__ __forceinline__ double block_sum(double x, double *sh) {
+  // fixed-shape tree: wave shuffle, then the 4 wave sums in order -> deterministic
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = x;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < BLOCK / 64; i++) r += sh[i];
+  }
+  return r; // valid in thread 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sweep of one shell for every source of the batch (blockIdx.y = source).
+// evolve0D, files_for_3D/evolve_point.F90:114-168 and :237-244, with cinterp
+// (column_density.f90:28-345); boundary photon loss :310-315.
+// col layout: [slot][6][ncell] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII).
+__global__ void __launch_bounds__(BLOCK)
+k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__restrict__ ndens,
+              const double *__restrict__ xh_av, const double *__restrict__ xhe_av, double *__restrict__ col,
+              const BandData *__restrict__ bd, const double *__restrict__ photo_thick,
+              const double *__restrict__ photo_thin, double *__restrict__ loss_partial, int max_blocks) {
+  __shared__ double sh[BLOCK / 64];
+  const SrcInfo &S = ba.s[blockIdx.y];
+  const long long cnt = shell_count(shell);
+  const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  double loss = 0.0;
+  if (t < cnt) {
+    int di, dj, dk;
+    shell_decode(shell, (int)t, di, dj, dk);
+    const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] &&
+                        dk <= S.hi[2];
+    if (inside) {
+      const size_t nc = g.ncell;
+      const size_t q = cell_index(g, S.i0, S.j0, S.k0, di, dj, dk);
+      double *cs = col + (size_t)S.slot * 6 * nc;
+      const double nd = ndens[q];
+      const double h0 = dmax(xh_av[q], epsilon);
+      const double he0 = dmax(xhe_av[q], epsilon);
+      const double he1 = dmax(xhe_av[q + nc], epsilon);
+      double cin_HI, cin_HeI, cin_HeII, path, vol_ph;
+      if (shell == 0) {
+        cin_HI = cin_HeI = cin_HeII = 0.0;
+        path = 0.5 * sc.dr1;
+        vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
+      } else {
+        ShortChar s4;
+        short_characteristic(S.i0, S.j0, S.k0, di, dj, dk, s4);
+        size_t qc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) qc[c] = cell_index(g, S.i0, S.j0, S.k0, s4.ci[c], s4.cj[c], s4.ck[c]);
+        const double *oH = cs + 3 * nc, *oHe0 = cs + 4 * nc, *oHe1 = cs + 5 * nc;
+        cin_HI = interp_column(s4, oH[qc[0]], oH[qc[1]], oH[qc[2]], oH[qc[3]], sigma_HI_at_ion_freq);
+        cin_HeI = interp_column(s4, oHe0[qc[0]], oHe0[qc[1]], oHe0[qc[2]], oHe0[qc[3]], sigma_HeI_at_ion_freq);
+        cin_HeII = interp_column(s4, oHe1[qc[0]], oHe1[qc[1]], oHe1[qc[2]], oHe1[qc[3]], sigma_HeII_at_ion_freq);
+        path = s4.path * sc.dr1;
+        const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
+        const double dist2 = xs * xs + ys * ys + zs * zs;
+        vol_ph = 4.0 * pi * dist2 * path;
+      }
+      const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
+      const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
+      const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
+      cs[q] = cin_HI;
+      cs[q + nc] = cin_HeI;
+      cs[q + 2 * nc] = cin_HeII;
+      cs[q + 3 * nc] = cout_HI;
+      cs[q + 4 * nc] = cout_HeI;
+      cs[q + 5 * nc] = cout_HeII;
+      const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
+                            dk == S.hi[2];
+      if (boundary && cin_HI < max_coldensh) {
+        const double po = photo_out_only(*bd, photo_thick, photo_thin, cin_HI, cout_HI, cin_HeI, cout_HeI,
+                                         cin_HeII, cout_HeII, S.nflux);
+        loss = po * sc.vol / vol_ph;
+      }
+    }
+  }
+  const double bs = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * max_blocks + blockIdx.x] = bs;
+}
+
+// photon_loss_src_thread(tn) += ... (evolve_point.F90:312): add this shell's block partials, in
+// block order, to the running loss of each source of the batch.
+__global__ void __launch_bounds__(64)
+k_loss_finish(const double *__restrict__ loss_partial, int max_blocks, int nblocks, double *__restrict__ loss_acc) {
+  if (threadIdx.x == 0) {
+    const double *p = loss_partial + (size_t)blockIdx.x * max_blocks;
+    double a = loss_acc[blockIdx.x];
+    for (int i = 0; i < nblocks; i++) a += p[i];
+    loss_acc[blockIdx.x] = a;
+  }
+}
+
+// path length of cinterp for an offset, without the corner work (column_density.f90:194,269,341)
+__device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
+  const int ia = idel < 0 ? -idel : idel, ja = jdel < 0 ? -jdel : jdel, ka = kdel < 0 ? -kdel : kdel;
+  const double di = (double)idel, dj = (double)jdel, dk = (double)kdel;
+  if (ka >= ja && ka >= ia) return sqrt((di * di + dj * dj) / (dk * dk) + 1.0);
+  if (ja >= ia && ja >= ka) return sqrt((di * di + dk * dk) / (dj * dj) + 1.0);
+  return sqrt(1.0 + (dj * dj + dk * dk) / (di * di));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rates of every cell from every source of the batch, accumulated in source order
+// (evolve_point.F90:246-306 with photoion_rates, radiation_photoionrates.f90:108-277).
+// rates layout: [phih | phihe0 | phihe1 | phiheat] each ncell.
+template <bool HEAT>
+__global__ void __launch_bounds__(BLOCK)
+k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
+        const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
+        const double *__restrict__ photo_thick, const double *__restrict__ photo_thin,
+        const double *__restrict__ heat_thick, const double *__restrict__ heat_thin, double *__restrict__ rates) {
+  const size_t nc = g.ncell;
+  const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (q >= nc) return;
+  const int i = (int)(q % g.n1), j = (int)((q / g.n1) % g.n2), k = (int)(q / ((size_t)g.n1 * g.n2));
+  const double nd = ndens[q];
+  const double h0 = dmax(xh_av[q], epsilon), h1 = dmax(xh_av[q + nc], epsilon);
+  const double he0 = dmax(xhe_av[q], epsilon), he1 = dmax(xhe_av[q + nc], epsilon);
+  double a_HI = rates[q], a_HeI = rates[q + nc], a_HeII = rates[q + 2 * nc];
+  double a_heat = HEAT ? rates[q + 3 * nc] : 0.0;
+  bool touched = false;
+  for (int b = 0; b < ba.n; b++) {
+    const SrcInfo &S = ba.s[b];
+    const double *cs = col + (size_t)S.slot * 6 * nc;
+    const double cout_HI = cs[q + 3 * nc];
+    if (cout_HI == 0.0) continue; // cell not reached by this source (evolve_point.F90:120, sub-box cut-off)
+    touched = true;
+    const double cin_HI = cs[q], cin_HeI = cs[q + nc], cin_HeII = cs[q + 2 * nc];
+    const double cout_HeI = cs[q + 4 * nc], cout_HeII = cs[q + 5 * nc];
+    // unwrapped offset rtpos - srcpos in [-mesh/2, mesh - mesh/2 - 1]
+    int di = i + 1 - S.i0, dj = j + 1 - S.j0, dk = k + 1 - S.k0;
+    di = wrap0(di + g.l1, g.n1) - g.l1;
+    dj = wrap0(dj + g.l2, g.n2) - g.l2;
+    dk = wrap0(dk + g.l3, g.n3) - g.l3;
+    double vol_ph;
+    if (di == 0 && dj == 0 && dk == 0) {
+      vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
+    } else {
+      const double path = sc_path(di, dj, dk) * sc.dr1;
+      const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
+      const double dist2 = xs * xs + ys * ys + zs * zs;
+      vol_ph = 4.0 * pi * dist2 * path;
+    }
+    if (cin_HI < max_coldensh) {
+      PhotoOut o;
+      photoion_rates<HEAT>(*bd, photo_thick, photo_thin, heat_thick, heat_thin, cin_HI, cout_HI, cin_HeI, cout_HeI,
+                           cin_HeII, cout_HeII, vol_ph, S.nflux, h1, o);
+      a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
+      a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);
+      a_HeII = a_HeII + o.photo_HeII / (he1 * nd * abu_he);
+      if (HEAT) a_heat = a_heat + o.heat;
+    } else {
+      // rates are zero: x + 0.0 == x
+    }
+  }
+  if (touched) {
+    rates[q] = a_HI;
+    rates[q + nc] = a_HeI;
+    rates[q + 2 * nc] = a_HeII;
+    if (HEAT) rates[q + 3 * nc] = a_heat;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// evolve0D_global + do_chemistry (files_for_3D/evolve_point.F90:325-440, :444-646), one cell per lane.
+template <bool HEAT>
+__global__ void __launch_bounds__(BLOCK)
+k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
+            const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
+            double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
+            const double *__restrict__ rates, int *__restrict__ conv_flag) {
+  const size_t nc = g.ncell;
+  const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  int notconv = 0;
+  if (q < nc) {
+    IonStates ion;
+    ion.h[0] = dmax(epsilon, xh_int[q]);       ion.h[1] = dmax(epsilon, xh_int[q + nc]);
+    ion.h_old[0] = dmax(epsilon, xh[q]);       ion.h_old[1] = dmax(epsilon, xh[q + nc]);
+    const double yh0_av_old = xh_av[q];
+    ion.h_av[0] = dmax(epsilon, yh0_av_old);   ion.h_av[1] = dmax(epsilon, xh_av[q + nc]);
+    ion.he[0] = dmax(epsilon, xhe_int[q]);     ion.he[1] = dmax(epsilon, xhe_int[q + nc]);
+    ion.he[2] = dmax(epsilon, xhe_int[q + 2 * nc]);
+    ion.he_old[0] = dmax(epsilon, xhe[q]);     ion.he_old[1] = dmax(epsilon, xhe[q + nc]);
+    ion.he_old[2] = dmax(epsilon, xhe[q + 2 * nc]);
+    const double yhe0_av_old = xhe_av[q], yhe2_av_old = xhe_av[q + 2 * nc];
+    ion.he_av[0] = dmax(epsilon, yhe0_av_old); ion.he_av[1] = dmax(epsilon, xhe_av[q + nc]);
+    ion.he_av[2] = dmax(epsilon, yhe2_av_old);
+    const double ndens_p = ndens[q];
+    const double phi_HI = rates[q], phi_HeI = rates[q + nc], phi_HeII = rates[q + 2 * nc];
+    const double heat = HEAT ? rates[q + 3 * nc] : 0.0;
+
+    // get_temperature_point (mat_ini_test.F90:469-487)
+    double avg_temper, temper1, temp_av_old;
+    if (HEAT) {
+      avg_temper = (double)temperature[q + nc];
+      temper1 = (double)temperature[q + 2 * nc];
+    } else {
+      avg_temper = sc.temper_val;
+      temper1 = sc.temper_val;
+    }
+    temp_av_old = avg_temper;
+    const double temper0 = temper1;
+    RecCoef rc = sc.rc;
+    const double path = 1.0;
+    int nit = 0;
+    for (;;) {
+      nit++;
+      const double temper2 = temper1;
+      const double h0_old = ion.h_av[0], he0_old = ion.he_av[0], he2_old = ion.he_av[2];
+      double de = electrondens(ndens_p, ion.h_av, ion.he_av);
+      if (HEAT) ini_rec_colion_factors(avg_temper, rc);
+
+      double yfrac, zfrac, y2afrac, y2bfrac;
+      prepare_doric_factors(coldens(path, ion.h[0], ndens_p, (1.0 - abu_he)), coldens(path, ion.he[0], ndens_p, abu_he),
+                            coldens(path, ion.he[1], ndens_p, abu_he), yfrac, zfrac, y2afrac, y2bfrac);
+      doric(dt, de, ion, phi_HI, phi_HeI, phi_HeII, yfrac, zfrac, y2afrac, y2bfrac, rc, sc.clumping);
+      de = electrondens(ndens_p, ion.h_av, ion.he_av);
+      prepare_doric_factors(coldens(path, ion.h[0], ndens_p, (1.0 - abu_he)), coldens(path, ion.he[0], ndens_p, abu_he),
+                            coldens(path, ion.he[1], ndens_p, abu_he), yfrac, zfrac, y2afrac, y2bfrac);
+      const double ionh0old = ion.h[0], ionh1old = ion.h[1];
+      const double ionhe0old = ion.he[0], ionhe1old = ion.he[1], ionhe2old = ion.he[2];
+      const double oldhav = ion.h_av[0], oldhe0av = ion.he_av[0], oldhe1av = ion.he_av[1];
+      doric(dt, de, ion, phi_HI, phi_HeI, phi_HeII, yfrac, zfrac, y2afrac, y2bfrac, rc, sc.clumping);
+      ion.h[0] = (ion.h[0] + ionh0old) / 2.0;
+      ion.h[1] = (ion.h[1] + ionh1old) / 2.0;
+      ion.he[0] = (ion.he[0] + ionhe0old) / 2.0;
+      ion.he[1] = (ion.he[1] + ionhe1old) / 2.0;
+      ion.he[2] = (ion.he[2] + ionhe2old) / 2.0;
+      ion.h_av[0] = (ion.h_av[0] + oldhav) / 2.0;
+      ion.he_av[0] = (ion.he_av[0] + oldhe0av) / 2.0;
+      ion.he_av[1] = (ion.he_av[1] + oldhe1av) / 2.0;
+      de = electrondens(ndens_p, ion.h_av, ion.he_av);
+      temper1 = temper0;
+      if (HEAT) thermal(sc.cd, dt, temper1, avg_temper, de, ndens_p, ion, heat);
+
+      const double mfc = minimum_fractional_change, mfa = minimum_fraction_of_atoms;
+      if ((fabs((ion.h_av[0] - h0_old) / ion.h_av[0]) < mfc || ion.h_av[0] < mfa) &&
+          (fabs((ion.he_av[0] - he0_old) / ion.he_av[0]) < mfc || ion.he_av[0] < mfa) &&
+          (fabs((ion.he_av[2] - he2_old) / ion.he_av[2]) < mfc || ion.he_av[2] < mfa) &&
+          fabs((temper1 - temper2) / temper1) < mfc)
+        break;
+      if (nit > 400) break;
+    }
+    double temp_av_new = temp_av_old;
+    if (HEAT) { // set_temperature_point (mat_ini_test.F90:491-502): stored as REAL(4)
+      const float t0 = (float)temper1, t1 = (float)avg_temper;
+      temperature[q] = t0;
+      temperature[q + nc] = t1;
+      temp_av_new = (double)t1;
+    }
+    const double mfc = minimum_fractional_change, mfa = minimum_fraction_of_atoms;
+    if ((fabs(ion.h_av[0] - yh0_av_old) > mfc && fabs((ion.h_av[0] - yh0_av_old) / ion.h_av[0]) > mfc &&
+         ion.h_av[0] > mfa) ||
+        (fabs(ion.he_av[0] - yhe0_av_old) > mfc && fabs((ion.he_av[0] - yhe0_av_old) / ion.he_av[0]) > mfc &&
+         ion.he_av[0] > mfa) ||
+        (fabs(ion.he_av[2] - yhe2_av_old) > mfc && fabs((ion.he_av[2] - yhe2_av_old) / ion.he_av[2]) > mfc &&
+         ion.he_av[2] > mfa) ||
+        (fabs((temp_av_old - temp_av_new) / temp_av_new) > 1.0e-1 && fabs(temp_av_new - temp_av_old) > 100.0))
+      notconv = 1;
+    xh_int[q] = ion.h[0];       xh_int[q + nc] = ion.h[1];
+    xh_av[q] = ion.h_av[0];     xh_av[q + nc] = ion.h_av[1];
+    xhe_int[q] = ion.he[0];     xhe_int[q + nc] = ion.he[1];     xhe_int[q + 2 * nc] = ion.he[2];
+    xhe_av[q] = ion.he_av[0];   xhe_av[q + nc] = ion.he_av[1];   xhe_av[q + 2 * nc] = ion.he_av[2];
+  }
+  // conv_flag = conv_flag + 1 (evolve_point.F90:423): integer count, order-independent
+  const unsigned long long m = __ballot(notconv);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(conv_flag, (int)__popcll(m));
+}
+
+} // namespace
+
+// =============================================================================================
+// host side
+struct c2r_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Grid g{};
+  std::string err;
+
+  double *d_photo_thick = nullptr, *d_photo_thin = nullptr, *d_heat_thick = nullptr, *d_heat_thin = nullptr;
+  BandData *d_bands = nullptr;
+  bool have_tables = false, have_heat_tables = false;
+  double *d_cool = nullptr;
+  bool have_cool = false;
+  double cool_mintemp = 1.0, cool_dtemp = 0.01;
+
+  double *d_ndens = nullptr;
+  StepScalars sc{};
+  double zred = 0, H0 = 0, Omega0 = 0;
+  int isothermal = 1;
+  bool have_step = false;
+
+  int nsrc = 0;
+  std::vector<int> srcpos;
+  std::vector<double> normflux;
+  double s_star = 0;
+
+  double *d_xh = nullptr, *d_xhe = nullptr, *d_xh_av = nullptr, *d_xhe_av = nullptr, *d_xh_int = nullptr,
+         *d_xhe_int = nullptr;
+  float *d_temp = nullptr;
+  bool have_state = false;
+
+  double *d_rates = nullptr, *d_rates_own = nullptr;
+  size_t rates_count = 0;
+
+  int batch = 8;
+  double *d_col = nullptr;
+  size_t col_slots = 0;
+  double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
+  int max_blocks = 0;
+  double *h_loss = nullptr; // pinned
+  int *d_conv = nullptr;
+  int *h_conv = nullptr;    // pinned
+  int last_slot = 0;
+
+  double photon_loss[C2R_NFREQ] = {0};
+  int sum_nbox = 0;
+
+  bool timing = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  c2r_timing tm{};
+};
+
+static std::string g_create_error;
+
+static int fail(c2r_ctx *c, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return 1;
+}
+#define HIPCHK(c, call)                                                                             \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char *c2r_last_error(const c2r_ctx *c) { return c ? c->err.c_str() : "null context"; }
+extern "C" const char *c2r_create_error(void) { return g_create_error.c_str(); }
+
+static int alloc_col(c2r_ctx *c) {
+  if (c->d_col && c->col_slots >= (size_t)c->batch) return 0;
+  if (c->d_col) HIPCHK(c, hipFree(c->d_col));
+  c->d_col = nullptr;
+  HIPCHK(c, hipMalloc(&c->d_col, sizeof(double) * 6 * c->g.ncell * c->batch));
+  c->col_slots = c->batch;
+  return 0;
+}
+
+extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
+  if (!out || !mesh) return fail(nullptr, "c2r_create: null argument");
+  if (mesh[0] < 2 || mesh[1] < 2 || mesh[2] < 2 || mesh[0] > 4096 || mesh[1] > 4096 || mesh[2] > 4096)
+    return fail(nullptr, "c2r_create: mesh %d x %d x %d out of range [2,4096]", mesh[0], mesh[1], mesh[2]);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, "c2r_create: no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(nullptr, "c2r_create: device %d not in [0,%d)", device, ndev);
+  c2r_ctx *c = new c2r_ctx;
+  c->device = device;
+  c->g.n1 = mesh[0]; c->g.n2 = mesh[1]; c->g.n3 = mesh[2];
+  c->g.l1 = mesh[0] / 2; c->g.l2 = mesh[1] / 2; c->g.l3 = mesh[2] / 2;
+  c->g.ncell = (size_t)mesh[0] * mesh[1] * mesh[2];
+  const size_t nc = c->g.ncell;
+#define CR(call)                                                                                    \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      fail(nullptr, "%s failed: %s", #call, hipGetErrorString(e_));                                 \
+      c2r_destroy(c);                                                                               \
+      return 1;                                                                                     \
+    }                                                                                               \
+  } while (0)
+  CR(hipSetDevice(device));
+  CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CR(hipMalloc(&c->d_ndens, sizeof(double) * nc));
+  CR(hipMalloc(&c->d_xh, sizeof(double) * 2 * nc));
+  CR(hipMalloc(&c->d_xhe, sizeof(double) * 3 * nc));
+  CR(hipMalloc(&c->d_xh_av, sizeof(double) * 2 * nc));
+  CR(hipMalloc(&c->d_xhe_av, sizeof(double) * 3 * nc));
+  CR(hipMalloc(&c->d_xh_int, sizeof(double) * 2 * nc));
+  CR(hipMalloc(&c->d_xhe_int, sizeof(double) * 3 * nc));
+  CR(hipMalloc(&c->d_temp, sizeof(float) * 3 * nc));
+  c->rates_count = 4 * nc + C2R_NFREQ + 1;
+  CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
+  c->d_rates = c->d_rates_own;
+  CR(hipMemset(c->d_rates, 0, sizeof(double) * c->rates_count)); // phih_grid = 0 for initial output (evolve_data.F90:77,80)
+  // largest shell: s = max extent
+  int smax = std::max(c->g.l1, std::max(c->g.l2, c->g.l3));
+  c->max_blocks = (int)((shell_count(smax) + BLOCK - 1) / BLOCK);
+  CR(hipMalloc(&c->d_loss_partial, sizeof(double) * (size_t)c->max_blocks * MAXB));
+  CR(hipMalloc(&c->d_loss_acc, sizeof(double) * MAXB));
+  CR(hipHostMalloc(&c->h_loss, sizeof(double) * MAXB));
+  CR(hipMalloc(&c->d_conv, sizeof(int)));
+  CR(hipHostMalloc(&c->h_conv, sizeof(int)));
+  CR(hipMalloc(&c->d_bands, sizeof(BandData)));
+  for (auto &ev : c->ev) CR(hipEventCreate(&ev));
+#undef CR
+  *out = c;
+  return 0;
+}
+
+extern "C" void c2r_destroy(c2r_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
+                  c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
+                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_loss) (void)hipHostFree(c->h_loss);
+  if (c->h_conv) (void)hipHostFree(c->h_conv);
+  for (auto &ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// host (0:NumTau, ncol) -> device columns of pitch NTAUP with row 2001 = row 2000
+static int upload_table(c2r_ctx *c, const double *src, int ncol, double **dst) {
+  std::vector<double> tmp((size_t)ncol * NTAUP);
+  for (int col = 0; col < ncol; col++) {
+    const double *s = src + (size_t)col * (NTAU + 1);
+    double *d = tmp.data() + (size_t)col * NTAUP;
+    std::memcpy(d, s, sizeof(double) * (NTAU + 1));
+    d[NTAU + 1] = s[NTAU];
+  }
+  if (!*dst) HIPCHK(c, hipMalloc(dst, sizeof(double) * tmp.size()));
+  HIPCHK(c, hipMemcpy(*dst, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const double *photo_thin,
+                              const double *heat_thick, const double *heat_thin, const double *sigma_HI,
+                              const double *sigma_HeI, const double *sigma_HeII, const double *const fvec[12],
+                              int bb_upper) {
+  if (!c) return 1;
+  if (!photo_thick || !photo_thin || !sigma_HI || !sigma_HeI || !sigma_HeII)
+    return fail(c, "c2r_set_tables: photo tables and cross sections are required");
+  if (bb_upper < 1 || bb_upper > NFREQ) return fail(c, "c2r_set_tables: bb_upper %d not in [1,%d]", bb_upper, NFREQ);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (upload_table(c, photo_thick, NFREQ, &c->d_photo_thick)) return 1;
+  if (upload_table(c, photo_thin, NFREQ, &c->d_photo_thin)) return 1;
+  c->have_heat_tables = false;
+  BandData bd;
+  std::memset(&bd, 0, sizeof bd);
+  std::memcpy(bd.sigma_HI, sigma_HI, sizeof bd.sigma_HI);
+  std::memcpy(bd.sigma_HeI, sigma_HeI, sizeof bd.sigma_HeI);
+  std::memcpy(bd.sigma_HeII, sigma_HeII, sizeof bd.sigma_HeII);
+  bd.bb_upper = bb_upper;
+  if (heat_thick && heat_thin) {
+    if (!fvec) return fail(c, "c2r_set_tables: heat tables given without the secondary-ionisation vectors");
+    for (int i = 0; i < 12; i++)
+      if (!fvec[i]) return fail(c, "c2r_set_tables: fvec[%d] is NULL", i);
+    if (upload_table(c, heat_thick, NHEAT, &c->d_heat_thick)) return 1;
+    if (upload_table(c, heat_thin, NHEAT, &c->d_heat_thin)) return 1;
+    double *dst[12] = {bd.f1ion_HI, bd.f1ion_HeI, bd.f1ion_HeII, bd.f2ion_HI, bd.f2ion_HeI, bd.f2ion_HeII,
+                       bd.f1heat_HI, bd.f1heat_HeI, bd.f1heat_HeII, bd.f2heat_HI, bd.f2heat_HeI, bd.f2heat_HeII};
+    for (int i = 0; i < 12; i++) std::memcpy(dst[i], fvec[i], sizeof(double) * (NFREQ - 1));
+    c->have_heat_tables = true;
+  }
+  HIPCHK(c, hipMemcpy(c->d_bands, &bd, sizeof bd, hipMemcpyHostToDevice));
+  c->have_tables = true;
+  return 0;
+}
+
+extern "C" int c2r_set_cooling(c2r_ctx *c, const double *cool, double mintemp, double dtemp) {
+  if (!c) return 1;
+  if (!cool || !(dtemp > 0.0)) return fail(c, "c2r_set_cooling: bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->d_cool) HIPCHK(c, hipMalloc(&c->d_cool, sizeof(double) * 5 * NCOOL));
+  HIPCHK(c, hipMemcpy(c->d_cool, cool, sizeof(double) * 5 * NCOOL, hipMemcpyHostToDevice));
+  c->cool_mintemp = mintemp;
+  c->cool_dtemp = dtemp;
+  c->have_cool = true;
+  return 0;
+}
+
+extern "C" int c2r_set_step(c2r_ctx *c, const double *ndens, const double dr[3], double vol, float clumping,
+                            double zred, double H0, double Omega0, int isothermal, double temper_val,
+                            const double reccoef[12]) {
+  if (!c) return 1;
+  if (!ndens || !dr || !reccoef) return fail(c, "c2r_set_step: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->d_ndens, ndens, sizeof(double) * c->g.ncell, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->sc.dr1 = dr[0]; c->sc.dr2 = dr[1]; c->sc.dr3 = dr[2]; c->sc.vol = vol;
+  c->sc.clumping = (double)clumping;
+  c->sc.temper_val = temper_val;
+  std::memcpy(&c->sc.rc, reccoef, sizeof(double) * 12);
+  c->zred = zred; c->H0 = H0; c->Omega0 = Omega0;
+  c->isothermal = isothermal ? 1 : 0;
+  c->have_step = true;
+  return 0;
+}
+
+extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const double *normflux, double s_star) {
+  if (!c) return 1;
+  if (nsrc < 0 || (nsrc > 0 && (!srcpos || !normflux))) return fail(c, "c2r_set_sources: bad arguments");
+  for (int s = 0; s < nsrc; s++) {
+    const int *p = srcpos + 3 * s;
+    if (p[0] < 1 || p[0] > c->g.n1 || p[1] < 1 || p[1] > c->g.n2 || p[2] < 1 || p[2] > c->g.n3)
+      return fail(c, "c2r_set_sources: source %d at (%d,%d,%d) outside the mesh", s + 1, p[0], p[1], p[2]);
+  }
+  c->nsrc = nsrc;
+  c->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
+  c->normflux.assign(normflux, normflux + nsrc);
+  c->s_star = s_star;
+  return 0;
+}
+
+extern "C" int c2r_upload_state(c2r_ctx *c, const double *xh, const double *xhe, const float *temperature) {
+  if (!c) return 1;
+  if (!xh || !xhe) return fail(c, "c2r_upload_state: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  HIPCHK(c, hipMemcpyAsync(c->d_xh, xh, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_xhe, xhe, sizeof(double) * 3 * nc, hipMemcpyHostToDevice, c->stream));
+  if (temperature)
+    HIPCHK(c, hipMemcpyAsync(c->d_temp, temperature, sizeof(float) * 3 * nc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_state = true;
+  return 0;
+}
+
+extern "C" int c2r_download_state(c2r_ctx *c, double *xh, double *xhe, float *temperature) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  if (xh) HIPCHK(c, hipMemcpyAsync(xh, c->d_xh, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+  if (xhe) HIPCHK(c, hipMemcpyAsync(xhe, c->d_xhe, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+  if (temperature)
+    HIPCHK(c, hipMemcpyAsync(temperature, c->d_temp, sizeof(float) * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int check_ready(c2r_ctx *c, const char *who) {
+  if (!c->have_tables) return fail(c, "%s: c2r_set_tables has not been called", who);
+  if (!c->have_step) return fail(c, "%s: c2r_set_step has not been called", who);
+  if (!c->have_state) return fail(c, "%s: c2r_upload_state has not been called", who);
+  if (!c->isothermal) {
+    if (!c->have_heat_tables) return fail(c, "%s: non-isothermal run needs the heating tables", who);
+    if (!c->have_cool) return fail(c, "%s: non-isothermal run needs c2r_set_cooling", who);
+  }
+  return 0;
+}
+
+static StepScalars scalars(c2r_ctx *c) {
+  StepScalars s = c->sc;
+  s.cd.cool = c->d_cool;
+  s.cd.mintemp = c->cool_mintemp;
+  s.cd.dtemp = c->cool_dtemp;
+  s.cd.zred = c->zred;
+  s.cd.H0 = c->H0;
+  s.cd.Omega0 = c->Omega0;
+  return s;
+}
+
+extern "C" int c2r_begin_step(c2r_ctx *c) {
+  if (!c) return 1;
+  if (!c->have_state) return fail(c, "c2r_begin_step: c2r_upload_state has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  HIPCHK(c, hipMemcpyAsync(c->d_xh_av, c->d_xh, sizeof(double) * 2 * nc, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_xh_int, c->d_xh, sizeof(double) * 2 * nc, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_xhe_av, c->d_xhe, sizeof(double) * 3 * nc, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_xhe_int, c->d_xhe, sizeof(double) * 3 * nc, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int c2r_end_step(c2r_ctx *c) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  HIPCHK(c, hipMemcpyAsync(c->d_xh, c->d_xh_int, sizeof(double) * 2 * nc, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_xhe, c->d_xhe_int, sizeof(double) * 3 * nc, hipMemcpyDeviceToDevice, c->stream));
+  if (!c->isothermal) // set_final_temperature_point (mat_ini_test.F90:505-515)
+    HIPCHK(c, hipMemcpyAsync(c->d_temp + 2 * nc, c->d_temp, sizeof(float) * nc, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+extern "C" int c2r_set_rates_to_zero(c2r_ctx *c) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemsetAsync(c->d_rates, 0, sizeof(double) * c->rates_count, c->stream));
+  std::memset(c->photon_loss, 0, sizeof c->photon_loss);
+  c->sum_nbox = 0;
+  return 0;
+}
+
+extern "C" int c2r_set_batch(c2r_ctx *c, int nbatch) {
+  if (!c) return 1;
+  if (nbatch < 1 || nbatch > MAXB) return fail(c, "c2r_set_batch: %d not in [1,%d]", nbatch, MAXB);
+  c->batch = nbatch;
+  return 0;
+}
+
+// host-side sub-box bookkeeping of one source (do_source, evolve_source.F90:96-144, 233-236)
+struct SrcRun {
+  int ns;                 // 1-based source number
+  int lastpos_r[3], lastpos_l[3]; // as offsets from srcpos
+  int last_r[3], last_l[3];       // current box, offsets
+  int nbox = 0;
+  double total_flux = 0, loss = 0;
+  bool active = true;
+  int smax_prev = -1;     // largest shell already swept
+};
+
+static int box_smax(const SrcRun &r) {
+  int m = 0;
+  for (int d = 0; d < 3; d++) m = std::max(m, std::max(r.last_r[d], -r.last_l[d]));
+  return m;
+}
+
+extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
+  if (!c) return 1;
+  if (check_ready(c, "c2r_pass_sources")) return 1;
+  if (first < 1 || stride < 1) return fail(c, "c2r_pass_sources: first=%d stride=%d", first, stride);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (alloc_col(c)) return 1;
+  const Grid g = c->g;
+  const size_t nc = g.ncell;
+  const StepScalars sc = scalars(c);
+  const int mesh[3] = {g.n1, g.n2, g.n3};
+  c->tm.sweep_ms = c->tm.rates_ms = 0.0;
+  c->tm.sweep_launches = c->tm.rates_launches = 0;
+  c->tm.cells_swept = 0;
+
+  std::vector<int> mine;
+  for (int ns = first; ns <= c->nsrc; ns += stride) mine.push_back(ns);
+
+  for (size_t b0 = 0; b0 < mine.size(); b0 += c->batch) {
+    const int nb = (int)std::min<size_t>(c->batch, mine.size() - b0);
+    std::vector<SrcRun> run(nb);
+    for (int b = 0; b < nb; b++) {
+      SrcRun &r = run[b];
+      r.ns = mine[b0 + b];
+      for (int d = 0; d < 3; d++) { // periodic_bc = .true. (evolve_source.F90:103-105)
+        r.lastpos_r[d] = std::min(MAX_SUBBOX, mesh[d] / 2 - 1 + mesh[d] % 2);
+        r.lastpos_l[d] = -std::min(MAX_SUBBOX, mesh[d] / 2);
+        r.last_r[d] = r.last_l[d] = 0;
+      }
+      r.total_flux = c->normflux[r.ns - 1] * c->s_star;
+      r.loss = r.total_flux;
+    }
+    // coldensh_out = 0, coldenshe_out = 0 for every new source (evolve_source.F90:94-95): the three
+    // outgoing-column grids of each slot (the incoming ones are fully overwritten where used)
+    for (int b = 0; b < nb; b++)
+      HIPCHK(c, hipMemsetAsync(c->d_col + ((size_t)b * 6 + 3) * nc, 0, sizeof(double) * 3 * nc, c->stream));
+
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    for (;;) {
+      // while-test of evolve_source.F90:136-139 per source
+      BatchArgs ba;
+      ba.n = 0;
+      int act_idx[MAXB];
+      int s_lo = 1 << 30, s_hi = -1;
+      for (int b = 0; b < nb; b++) {
+        SrcRun &r = run[b];
+        if (!r.active) continue;
+        if (!(r.loss > C2R_F(1e-10) * r.total_flux && r.last_r[2] < r.lastpos_r[2] && r.last_l[2] > r.lastpos_l[2])) {
+          r.active = false;
+          continue;
+        }
+        r.nbox++;
+        r.loss = 0.0;
+        for (int d = 0; d < 3; d++) {
+          r.last_r[d] = std::min(SUBBOXSIZE * r.nbox, r.lastpos_r[d]);
+          r.last_l[d] = std::max(-SUBBOXSIZE * r.nbox, r.lastpos_l[d]);
+        }
+        SrcInfo &S = ba.s[ba.n];
+        const int *p = &c->srcpos[3 * (size_t)(r.ns - 1)];
+        S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
+        for (int d = 0; d < 3; d++) { S.lo[d] = r.last_l[d]; S.hi[d] = r.last_r[d]; }
+        S.nflux = c->normflux[r.ns - 1];
+        S.slot = b;
+        S.pad = 0;
+        act_idx[ba.n] = b;
+        ba.n++;
+        s_lo = std::min(s_lo, r.smax_prev + 1);
+        s_hi = std::max(s_hi, box_smax(r));
+      }
+      if (ba.n == 0) break;
+      HIPCHK(c, hipMemsetAsync(c->d_loss_acc, 0, sizeof(double) * MAXB, c->stream));
+      // All active sources of a batch are in the same sub-box round (same nbox history is not
+      // required: a source that stopped early simply is not in `ba`), so their new shells are
+      // s_prev+1 .. smax of the new box; sources whose box does not reach a shell skip it by the
+      // in-box test of the kernel.
+      for (int s = s_lo; s <= s_hi; s++) {
+        const long long cnt = shell_count(s);
+        const int nblk = (int)((cnt + BLOCK - 1) / BLOCK);
+        if (nblk > c->max_blocks) return fail(c, "internal: shell %d needs %d blocks > %d", s, nblk, c->max_blocks);
+        hipLaunchKernelGGL(k_sweep_shell, dim3(nblk, ba.n), dim3(BLOCK), 0, c->stream, g, ba, s, sc, c->d_ndens,
+                           c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin,
+                           c->d_loss_partial, c->max_blocks);
+        hipLaunchKernelGGL(k_loss_finish, dim3(ba.n), dim3(64), 0, c->stream, c->d_loss_partial, c->max_blocks, nblk,
+                           c->d_loss_acc);
+        c->tm.sweep_launches += 2;
+      }
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * MAXB, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (int a = 0; a < ba.n; a++) {
+        SrcRun &r = run[act_idx[a]];
+        r.loss = c->h_loss[a];
+        // cells traced in this round: the part of the new box not in the previous one
+        long long vol_new = 1, vol_old = 1;
+        for (int d = 0; d < 3; d++) {
+          vol_new *= (r.last_r[d] - r.last_l[d] + 1);
+          const int pr = std::min(SUBBOXSIZE * (r.nbox - 1), r.lastpos_r[d]);
+          const int pl = std::max(-SUBBOXSIZE * (r.nbox - 1), r.lastpos_l[d]);
+          vol_old *= (pr - pl + 1);
+        }
+        c->tm.cells_swept += r.nbox == 1 ? vol_new : vol_new - vol_old;
+        r.smax_prev = box_smax(r);
+      }
+    }
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+
+    // rates of the whole batch, in source order
+    BatchArgs ba;
+    ba.n = nb;
+    for (int b = 0; b < nb; b++) {
+      SrcInfo &S = ba.s[b];
+      const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
+      S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
+      for (int d = 0; d < 3; d++) { S.lo[d] = run[b].last_l[d]; S.hi[d] = run[b].last_r[d]; }
+      S.nflux = c->normflux[run[b].ns - 1];
+      S.slot = b;
+      S.pad = 0;
+    }
+    const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
+    if (c->isothermal)
+      hipLaunchKernelGGL(k_rates<false>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, ba, sc, c->d_ndens, c->d_xh_av,
+                         c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
+                         c->d_heat_thin, c->d_rates);
+    else
+      hipLaunchKernelGGL(k_rates<true>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, ba, sc, c->d_ndens, c->d_xh_av,
+                         c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
+                         c->d_heat_thin, c->d_rates);
+    HIPCHK(c, hipGetLastError());
+    c->tm.rates_launches++;
+    if (c->timing) {
+      HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+      HIPCHK(c, hipEventSynchronize(c->ev[2]));
+      float ms = 0;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+      c->tm.sweep_ms += ms;
+      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
+      c->tm.rates_ms += ms;
+    }
+    // photon_loss(1) += photon_loss_src ; sum_nbox += nbox  (evolve_source.F90:233-236), source order
+    for (int b = 0; b < nb; b++) {
+      c->photon_loss[0] = c->photon_loss[0] + run[b].loss;
+      c->sum_nbox += run[b].nbox;
+    }
+    c->last_slot = nb - 1;
+  }
+  // tail of the reduction buffer: photon_loss(1:47), sum_nbox
+  double tail[C2R_NFREQ + 1];
+  std::memcpy(tail, c->photon_loss, sizeof c->photon_loss);
+  tail[C2R_NFREQ] = (double)c->sum_nbox;
+  HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * nc, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
+  if (!c) return 1;
+  if (check_ready(c, "c2r_global_pass")) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const Grid g = c->g;
+  const StepScalars sc = scalars(c);
+  const int nblk = (int)((g.ncell + BLOCK - 1) / BLOCK);
+  HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (c->isothermal)
+    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv);
+  else
+    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv);
+  HIPCHK(c, hipGetLastError());
+  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->timing) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
+    c->tm.chem_ms = ms;
+    c->tm.chem_launches = 1;
+  }
+  if (conv_flag) *conv_flag = *c->h_conv;
+  return 0;
+}
+
+extern "C" int c2r_evolve3d(c2r_ctx *c, double dt, int *niter_out, int *conv_flags_out, int cap) {
+  if (!c) return 1;
+  if (check_ready(c, "c2r_evolve3d")) return 1;
+  if (c2r_begin_step(c)) return 1;
+  int niter = 0;
+  const Grid g = c->g;
+  int conv_flag = (int)g.ncell;
+  const int conv_criterion = std::min((int)(convergence_fraction * g.n1 * g.n2 * g.n3), c->nsrc); // evolve.F90:147
+  for (;;) {
+    if (conv_flag < conv_criterion && niter > 1) { // evolve.F90:163
+      if (c2r_end_step(c)) return 1;
+      break;
+    } else if (niter > 500) {
+      break;
+    }
+    niter++;
+    if (c2r_set_rates_to_zero(c)) return 1;
+    if (c->nsrc > 0 && c2r_pass_sources(c, 1, 1)) return 1;
+    if (c2r_global_pass(c, dt, &conv_flag)) return 1;
+    if (conv_flags_out && niter <= cap) conv_flags_out[niter - 1] = conv_flag;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (niter_out) *niter_out = niter;
+  return 0;
+}
+
+extern "C" int c2r_download_rates(c2r_ctx *c, double *phih, double *phihe, double *phiheat, double *photon_loss47,
+                                  int *sum_nbox) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  if (phih) HIPCHK(c, hipMemcpyAsync(phih, c->d_rates, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
+  if (phihe) HIPCHK(c, hipMemcpyAsync(phihe, c->d_rates + nc, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+  if (phiheat) HIPCHK(c, hipMemcpyAsync(phiheat, c->d_rates + 3 * nc, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
+  double tail[C2R_NFREQ + 1];
+  HIPCHK(c, hipMemcpyAsync(tail, c->d_rates + 4 * nc, sizeof tail, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (photon_loss47) std::memcpy(photon_loss47, tail, sizeof(double) * C2R_NFREQ);
+  if (sum_nbox) *sum_nbox = (int)(tail[C2R_NFREQ] + 0.5);
+  return 0;
+}
+
+extern "C" int c2r_download_iter_state(c2r_ctx *c, double *xh_av, double *xhe_av, double *xh_intermed,
+                                       double *xhe_intermed) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  if (xh_av) HIPCHK(c, hipMemcpyAsync(xh_av, c->d_xh_av, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+  if (xhe_av) HIPCHK(c, hipMemcpyAsync(xhe_av, c->d_xhe_av, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+  if (xh_intermed)
+    HIPCHK(c, hipMemcpyAsync(xh_intermed, c->d_xh_int, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+  if (xhe_intermed)
+    HIPCHK(c, hipMemcpyAsync(xhe_intermed, c->d_xhe_int, sizeof(double) * 3 * nc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int c2r_upload_rates(c2r_ctx *c, const double *phih, const double *phihe, const double *phiheat) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  if (phih) HIPCHK(c, hipMemcpyAsync(c->d_rates, phih, sizeof(double) * nc, hipMemcpyHostToDevice, c->stream));
+  if (phihe) HIPCHK(c, hipMemcpyAsync(c->d_rates + nc, phihe, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
+  if (phiheat) HIPCHK(c, hipMemcpyAsync(c->d_rates + 3 * nc, phiheat, sizeof(double) * nc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int c2r_upload_iter_state(c2r_ctx *c, const double *xh_av, const double *xhe_av, const double *xh_intermed,
+                                     const double *xhe_intermed) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  if (xh_av) HIPCHK(c, hipMemcpyAsync(c->d_xh_av, xh_av, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
+  if (xhe_av) HIPCHK(c, hipMemcpyAsync(c->d_xhe_av, xhe_av, sizeof(double) * 3 * nc, hipMemcpyHostToDevice, c->stream));
+  if (xh_intermed)
+    HIPCHK(c, hipMemcpyAsync(c->d_xh_int, xh_intermed, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
+  if (xhe_intermed)
+    HIPCHK(c, hipMemcpyAsync(c->d_xhe_int, xhe_intermed, sizeof(double) * 3 * nc, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int c2r_download_columns(c2r_ctx *c, double *coldensh_out, double *coldenshe_out) {
+  if (!c) return 1;
+  if (!c->d_col) return fail(c, "c2r_download_columns: no source has been swept yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nc = c->g.ncell;
+  const double *cs = c->d_col + (size_t)c->last_slot * 6 * nc;
+  if (coldensh_out) HIPCHK(c, hipMemcpyAsync(coldensh_out, cs + 3 * nc, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
+  if (coldenshe_out)
+    HIPCHK(c, hipMemcpyAsync(coldenshe_out, cs + 4 * nc, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" size_t c2r_rates_count(const c2r_ctx *c) { return c ? c->rates_count : 0; }
+extern "C" void *c2r_rates_device_ptr(c2r_ctx *c) { return c ? (void *)c->d_rates : nullptr; }
+extern "C" int c2r_set_rates_buffer(c2r_ctx *c, void *device_ptr, size_t count) {
+  if (!c) return 1;
+  if (!device_ptr) { c->d_rates = c->d_rates_own; return 0; }
+  if (count < c->rates_count) return fail(c, "c2r_set_rates_buffer: %zu doubles given, %zu needed", count, c->rates_count);
+  c->d_rates = (double *)device_ptr;
+  return 0;
+}
+extern "C" int c2r_synchronize(c2r_ctx *c) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int c2r_enable_timing(c2r_ctx *c, int on) {
+  if (!c) return 1;
+  c->timing = on != 0;
+  return 0;
+}
+extern "C" int c2r_get_timing(c2r_ctx *c, c2r_timing *out) {
+  if (!c || !out) return 1;
+  *out = c->tm;
+  return 0;
+}

@@ -1,0 +1,252 @@
+// exp, log10 and pow that return, bit for bit, what the reference's own libm returns.
+//
+// The reference (flang build, dynamically linked) gets exp, log10 and ** from glibc 2.35's libm on
+// x86-64; on every CPU with FMA+AVX2 its ifunc resolvers pick __exp_fma, __log_fma and __pow_fma
+// (ARM optimized-routines' exp.c / log.c / pow.c compiled with -mfma, so GCC fused many a*b+c);
+// log10 is the generic fdlibm __ieee754_log10 wrapper around that log.  evolve3D's outer iteration
+// amplifies a last-bit difference in any of these to the per-cent level in ionisation-front cells
+// (DESIGN.md "Conditioning"), and the device libm (ocml) differs from glibc in 1-23 % of calls
+// (tests/test_gpu_math.py).  So the functions below restate the three routines operation by
+// operation, with an explicit fma() exactly where the x86 build has a fused instruction and
+// separate roundings everywhere else (the file must be compiled with -ffp-contract=off).
+// Tables: csrc/c2ray_math_tables.hpp (generated, data only).
+//
+// Domain: finite, positive, normal arguments as they occur on the hot path; anything else (zero,
+// negative, subnormal, inf, nan, |y| < 2^-65 or >= 2^63 in pow) is forwarded to the platform libm.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define C2R_MHD __host__ __device__ __forceinline__
+#else
+#define C2R_MHD inline
+#endif
+
+namespace c2r {
+namespace gm {
+
+#define C2R_TAB static const
+#define C2R_TN(n) h_##n
+#include "c2ray_math_tables.hpp"
+#undef C2R_TAB
+#undef C2R_TN
+#if defined(__HIPCC__)
+#define C2R_TAB static __device__ const
+#define C2R_TN(n) d_##n
+#include "c2ray_math_tables.hpp"
+#undef C2R_TAB
+#undef C2R_TN
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GMT(n) d_##n
+#else
+#define GMT(n) h_##n
+#endif
+
+C2R_MHD uint64_t asuint64(double x) { return __builtin_bit_cast(uint64_t, x); }
+C2R_MHD double asdouble(uint64_t u) { return __builtin_bit_cast(double, u); }
+C2R_MHD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- log: __log_fma ---------------------------------------------------------------------------
+// precondition: x finite, positive, normal
+C2R_MHD double log_core(double x) {
+  const double *H = GMT(log_hdr);
+  const double Ln2hi = H[0], Ln2lo = H[1];
+  const double *A = H + 2, *B = H + 7;
+  const uint64_t ix = asuint64(x);
+  const uint64_t LO = 0x3FEE000000000000ULL; // asuint64(1.0 - 0x1p-4)
+  const uint64_t HI = 0x3FF1090000000000ULL; // asuint64(1.0 + 0x1.09p-4)
+  if (ix - LO < HI - LO) {
+    if (ix == 0x3FF0000000000000ULL) return 0.0;
+    const double r = x - 1.0;
+    const double u1 = fma_(r, B[2], B[1]);
+    const double u2 = fma_(r, B[5], B[4]);
+    const double r2 = r * r;
+    const double u3 = fma_(r, B[8], B[7]);
+    const double v1 = fma_(r2, B[3], u1);
+    const double v2 = fma_(r2, B[6], u2);
+    const double r3 = r * r2;
+    double v3 = fma_(r2, B[9], u3);
+    v3 = fma_(r3, B[10], v3);
+    const double w2 = fma_(v3, r3, v2);
+    const double P = fma_(w2, r3, v1);
+    const double t = fma_(r, 0x1p27, r);
+    const double rhi = fma_(-0x1p27, r, t);
+    const double rhi2 = rhi * rhi;
+    const double rlo = r - rhi;
+    const double hi = fma_(rhi2, B[0], r);
+    const double lo = fma_(rhi2, B[0], r - hi);
+    const double lo2 = fma_(B[0] * rlo, r + rhi, lo);
+    const double y = fma_(P, r3, lo2);
+    return hi + y;
+  }
+  const uint64_t tmp = ix - 0x3FE6000000000000ULL; // OFF
+  const int i = (int)((tmp >> 45) & 127);
+  const int k = (int)((int64_t)tmp >> 52);
+  const uint64_t iz = ix - (tmp & 0xFFF0000000000000ULL);
+  const double invc = GMT(log_tab)[2 * i], logc = GMT(log_tab)[2 * i + 1];
+  const double z = asdouble(iz);
+  const double kd = (double)k;
+  const double r = fma_(z, invc, -1.0);
+  const double w = fma_(kd, Ln2hi, logc);
+  const double t1 = fma_(r, A[2], A[1]);
+  const double hi = r + w;
+  const double r2 = r * r;
+  double lo = (w - hi) + r;
+  lo = fma_(kd, Ln2lo, lo);
+  const double r3 = r * r2;
+  const double t2 = fma_(r, A[4], A[3]);
+  const double s = fma_(r2, A[0], lo);
+  const double p = fma_(t2, r2, t1);
+  const double q = fma_(r3, p, s);
+  return q + hi;
+}
+
+// ---- log10: __ieee754_log10 (sysdeps/ieee754/dbl-64/e_log10.c, generic build, no fma) ----------
+C2R_MHD double log10_(double x) {
+  const uint64_t ix = asuint64(x);
+  if (ix - 0x0010000000000000ULL >= 0x7FF0000000000000ULL - 0x0010000000000000ULL) return ::log10(x);
+  const double ivln10 = asdouble(0x3FDBCB7B1526E50EULL);
+  const double log10_2hi = asdouble(0x3FD34413509F6000ULL);
+  const double log10_2lo = asdouble(0x3D59FEF311F12B36ULL);
+  int k = (int)(ix >> 52) - 1023;
+  const int i = k < 0 ? 1 : 0;
+  const uint64_t hx = (ix & 0x000FFFFFFFFFFFFFULL) | ((uint64_t)(0x3ff - i) << 52);
+  const double y = (double)(k + i);
+  const double z = y * log10_2lo + ivln10 * log_core(asdouble(hx));
+  return z + y * log10_2hi;
+}
+
+// ---- exp: __exp_fma ----------------------------------------------------------------------------
+C2R_MHD double exp_special(double tmp, uint64_t sbits, uint64_t ki) {
+  if ((ki & 0x80000000ULL) == 0) { // k > 0: the exponent of scale might have overflowed
+    sbits -= 1009ULL << 52;
+    const double scale = asdouble(sbits);
+    return 0x1p1009 * fma_(scale, tmp, scale);
+  }
+  sbits += 1022ULL << 52; // k < 0: careful in the subnormal range
+  const double scale = asdouble(sbits);
+  const double st = scale * tmp;
+  double y = scale + st;
+  if (y < 1.0) {
+    const double hi = 1.0 + y;
+    const double lo = (scale - y) + st;
+    double t = 1.0 - hi;
+    t = t + y;
+    t = t + lo;
+    y = (t + hi) - 1.0;
+    if (y == 0.0) y = 0.0;
+  }
+  return 0x1p-1022 * y;
+}
+
+// shared tail of exp and pow's exp_inline: r already reduced, ki = bits of the shifted k
+C2R_MHD double exp_poly(double r, uint64_t ki, uint32_t abstop) {
+  const double *H = GMT(exp_hdr);
+  const double C2 = H[4], C3 = H[5], C4 = H[6], C5 = H[7];
+  const int idx = 2 * (int)(ki & 127);
+  const uint64_t top = ki << 45;
+  const double tail = asdouble(GMT(exp_tab)[idx]);
+  const uint64_t sbits = GMT(exp_tab)[idx + 1] + top;
+  const double a = fma_(r, C3, C2);
+  const double b = r + tail;
+  const double r2 = r * r;
+  const double c = fma_(r, C5, C4);
+  const double d = fma_(a, r2, b);
+  const double r4 = r2 * r2;
+  const double tmp = fma_(r4, c, d);
+  if (abstop == 0) return exp_special(tmp, sbits, ki);
+  const double scale = asdouble(sbits);
+  return fma_(scale, tmp, scale);
+}
+
+C2R_MHD double exp_(double x) {
+  const double *H = GMT(exp_hdr);
+  const double InvLn2N = H[0], Shift = H[1], NegLn2hiN = H[2], NegLn2loN = H[3];
+  uint32_t abstop = (uint32_t)(asuint64(x) >> 52) & 0x7ff;
+  if (abstop - 0x3c9u > 0x3eu) {
+    if ((int32_t)(abstop - 0x3c9u) < 0) return 1.0 + x; // |x| < 2^-54
+    if (abstop >= 0x409u) {                            // |x| >= 1024, inf, nan
+      if (asuint64(x) == 0xFFF0000000000000ULL) return 0.0;
+      if (abstop >= 0x7ffu) return 1.0 + x;
+      return (asuint64(x) >> 63) ? 0.0 : (double)INFINITY;
+    }
+    abstop = 0; // 512 <= |x| < 1024: handled by exp_special
+  }
+  const double kds = fma_(x, InvLn2N, Shift);
+  const uint64_t ki = asuint64(kds);
+  const double kd = kds - Shift;
+  double r = fma_(kd, NegLn2hiN, x);
+  r = fma_(kd, NegLn2loN, r);
+  return exp_poly(r, ki, abstop);
+}
+
+// ---- pow: __pow_fma ----------------------------------------------------------------------------
+C2R_MHD double pow_(double x, double y) {
+  const uint64_t ix = asuint64(x), iy = asuint64(y);
+  const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
+  if (topx - 1u > 0x7fdu || (topy & 0x7ffu) - 0x3beu > 0x7fu) return ::pow(x, y);
+  // log_inline
+  const double *H = GMT(pow_hdr);
+  const double Ln2hi = H[0], Ln2lo = H[1];
+  const double *A = H + 2;
+  const uint64_t tmp = ix - 0x3FE6955500000000ULL; // OFF
+  const int i = (int)((tmp >> 45) & 127);
+  const int k = (int)((int64_t)tmp >> 52);
+  const uint64_t iz = ix - (tmp & 0xFFF0000000000000ULL);
+  const double z = asdouble(iz);
+  const double kd = (double)k;
+  const double invc = GMT(pow_tab)[3 * i], logc = GMT(pow_tab)[3 * i + 1], logctail = GMT(pow_tab)[3 * i + 2];
+  const double t1 = fma_(kd, Ln2hi, logc);
+  const double r = fma_(z, invc, -1.0);
+  const double ar = r * A[0];
+  const double lo1 = fma_(kd, Ln2lo, logctail);
+  const double q1 = fma_(r, A[2], A[1]);
+  const double q2 = fma_(r, A[4], A[3]);
+  const double t2 = r + t1;
+  const double ar2 = r * ar;
+  const double ar3 = r * ar2;
+  const double lo3 = fma_(ar, r, -ar2);
+  const double lo2 = (t1 - t2) + r;
+  const double q3 = fma_(r, A[6], A[5]);
+  const double hi = t2 + ar2;
+  const double q4 = fma_(q3, ar2, q2);
+  const double lo4 = (t2 - hi) + ar2;
+  const double q5 = fma_(ar2, q4, q1);
+  double lo = lo1 + lo2;
+  lo = lo + lo3;
+  lo = lo + lo4;
+  lo = fma_(ar3, q5, lo);
+  const double lhi = hi + lo;
+  const double ltail = (hi - lhi) + lo;
+  const double ehi = y * lhi;
+  const double elo = fma_(y, ltail, fma_(lhi, y, -ehi));
+  // exp_inline(ehi, elo, sign_bias = 0)
+  const double *E = GMT(exp_hdr);
+  const double InvLn2N = E[0], Shift = E[1], NegLn2hiN = E[2], NegLn2loN = E[3];
+  uint32_t abstop = (uint32_t)(asuint64(ehi) >> 52) & 0x7ff;
+  if (abstop - 0x3c9u > 0x3eu) {
+    if ((int32_t)(abstop - 0x3c9u) < 0) return 1.0 + ehi;
+    if (abstop >= 0x409u) return (asuint64(ehi) >> 63) ? 0.0 : (double)INFINITY;
+    abstop = 0;
+  }
+  const double kds = fma_(ehi, InvLn2N, Shift);
+  const uint64_t ki = asuint64(kds);
+  const double kd2 = kds - Shift;
+  double rr = fma_(kd2, NegLn2hiN, ehi);
+  rr = fma_(kd2, NegLn2loN, rr);
+  rr = elo + rr;
+  return exp_poly(rr, ki, abstop);
+}
+
+#undef GMT
+} // namespace gm
+} // namespace c2r
+
+// route the physics through these (c2ray_device.hpp checks for C2R_MATH_EXP)
+#define C2R_MATH_EXP(x) ::c2r::gm::exp_(x)
+#define C2R_MATH_LOG10(x) ::c2r::gm::log10_(x)
+#define C2R_MATH_POW(x, y) ::c2r::gm::pow_(x, y)

@@ -1,0 +1,351 @@
+"""Host-side mirror of the reference's `evolve` / `evolve_data` modules for a Python host.
+
+The reference's drop-in boundary is a set of Fortran modules with fixed public names
+(SURVEY.md section 8b); fortran/ holds those modules for a Fortran host.  This file offers the
+same call surface to Python (tests, bench.py): the same names, argument meaning and state
+ownership -- the *host* owns ndens, xh, xhe, temperature_grid, srcpos, NormFlux; `Evolve` owns the
+work arrays (phih_grid, xh_av, ...) which live on the GPU and are downloaded on request.
+
+    material / grid / sourceprops state  ->  Evolve.evolve3D(time, dt, restart)
+                                             (files_for_3D/evolve.F90:78-229)
+
+All numerical work happens in libc2ray_hip.so (HIP, gfx950).  There is no CPU fallback here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from ._lib import C2RayHipError, NFREQ
+
+PKG = Path(__file__).resolve().parent
+DEFAULT_TABLES = PKG / "data" / "rad_tables_bb5e4.npz"
+
+FVEC_ORDER = ["f1ion_HI", "f1ion_HeI", "f1ion_HeII", "f2ion_HI", "f2ion_HeI", "f2ion_HeII",
+              "f1heat_HI", "f1heat_HeI", "f1heat_HeII", "f2heat_HI", "f2heat_HeI", "f2heat_HeII"]
+
+convergence_fraction = float(np.float32(2.5e-4))  # c2ray_parameters.f90:26 (REAL(4) literal)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@dataclass
+class RadiationTables:
+    """What rad_ini (radiation_tables.f90:141-168) and setup_cool (cooling_h.f90:76-171) leave
+    behind: inputs of the hot path, built once on the host."""
+    photo_thick: np.ndarray
+    photo_thin: np.ndarray
+    heat_thick: np.ndarray | None
+    heat_thin: np.ndarray | None
+    sigma_HI: np.ndarray
+    sigma_HeI: np.ndarray
+    sigma_HeII: np.ndarray
+    fvec: dict
+    bb_upper: int
+    cool: np.ndarray | None = None
+    cool_mintemp: float = 1.0
+    cool_dtemp: float = 0.01
+
+    @classmethod
+    def load(cls, path=DEFAULT_TABLES):
+        with np.load(path) as z:
+            g = lambda k: _f64(z[k]) if k in z.files else None
+            return cls(g("photo_thick"), g("photo_thin"), g("heat_thick"), g("heat_thin"), g("sigma_HI"),
+                       g("sigma_HeI"), g("sigma_HeII"), {k: g(k) for k in FVEC_ORDER if k in z.files},
+                       int(z["bb_upper"]), g("cool"),
+                       float(z["cool_mintemp"]) if "cool_mintemp" in z.files else 1.0,
+                       float(z["cool_dtemp"]) if "cool_dtemp" in z.files else 0.01)
+
+
+@dataclass
+class Material:
+    """module material (files_for_3D/mat_ini_test.F90:27-36): host-owned state arrays, Fortran
+    layout flattened (i fastest, component slowest)."""
+    ndens: np.ndarray            # (N^3,) float64
+    xh: np.ndarray               # (2*N^3,) float64, components 0:1
+    xhe: np.ndarray              # (3*N^3,) float64, components 0:2
+    temperature_grid: np.ndarray | None = None  # (3*N^3,) float32, slots 0:2; None when isothermal
+    isothermal: bool = True
+    temper_val: float = 1.0e4
+    clumping: float = 1.0
+    reccoef: np.ndarray = field(default_factory=lambda: np.zeros(12))  # cgsconstants.f90:106-133
+
+
+@dataclass
+class GridProps:
+    """module grid (files_for_3D/grid.F90): cell sizes and volume (proper cm, cm^3)."""
+    mesh: tuple
+    dr: tuple
+    vol: float
+
+
+@dataclass
+class SourceProps:
+    """module sourceprops (files_for_3D/sourceprops_test.F90:38-40)."""
+    srcpos: np.ndarray           # (NumSrc, 3) int32, 1-based mesh coordinates
+    NormFlux: np.ndarray         # (NumSrc,) photons/s divided by S_star
+    S_star: float = 1.0e48
+
+    @property
+    def NumSrc(self):
+        return int(len(self.NormFlux))
+
+
+@dataclass
+class Cosmology:
+    zred: float = 0.0
+    H0: float = 0.0
+    Omega0: float = 0.0
+
+
+class HipEngine:
+    """Thin object wrapper over the C ABI (one context = one GPU)."""
+
+    def __init__(self, mesh, device=0):
+        self.lib = _lib.load()
+        self.mesh = tuple(int(m) for m in mesh)
+        self.ncell = int(np.prod(self.mesh))
+        h = C.c_void_p()
+        m = (C.c_int * 3)(*self.mesh)
+        if self.lib.c2r_create(C.byref(h), int(device), m) != 0:
+            raise C2RayHipError(self.lib.c2r_create_error().decode())
+        self.h = h
+        self._ext_rates = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.c2r_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise C2RayHipError(self.lib.c2r_last_error(self.h).decode())
+
+    # -- inputs ------------------------------------------------------------------------------
+    def set_tables(self, t: RadiationTables):
+        fv = None
+        if t.heat_thick is not None:
+            arr = (C.POINTER(C.c_double) * 12)(*[_dp(t.fvec[k]) for k in FVEC_ORDER])
+            fv = arr
+        self._chk(self.lib.c2r_set_tables(self.h, _dp(t.photo_thick), _dp(t.photo_thin), _dp(t.heat_thick),
+                                          _dp(t.heat_thin), _dp(t.sigma_HI), _dp(t.sigma_HeI), _dp(t.sigma_HeII),
+                                          fv, int(t.bb_upper)))
+        if t.cool is not None:
+            self._chk(self.lib.c2r_set_cooling(self.h, _dp(t.cool), float(t.cool_mintemp), float(t.cool_dtemp)))
+
+    def set_step(self, mat: Material, grid: GridProps, cosmo: Cosmology):
+        nd = _f64(mat.ndens).reshape(-1)
+        assert nd.size == self.ncell, "ndens has the wrong size"
+        dr = (C.c_double * 3)(*[float(x) for x in grid.dr])
+        rc = _f64(mat.reccoef).reshape(-1)
+        assert rc.size == 12
+        self._chk(self.lib.c2r_set_step(self.h, _dp(nd), dr, float(grid.vol), float(mat.clumping), float(cosmo.zred),
+                                        float(cosmo.H0), float(cosmo.Omega0), int(bool(mat.isothermal)),
+                                        float(mat.temper_val), _dp(rc)))
+
+    def set_sources(self, src: SourceProps):
+        pos = np.ascontiguousarray(src.srcpos, dtype=np.int32).reshape(-1)
+        nf = _f64(src.NormFlux).reshape(-1)
+        assert pos.size == 3 * nf.size
+        self._chk(self.lib.c2r_set_sources(self.h, int(nf.size), pos.ctypes.data_as(C.POINTER(C.c_int)), _dp(nf),
+                                           float(src.S_star)))
+        self.nsrc = int(nf.size)
+
+    def upload_state(self, mat: Material):
+        xh, xhe = _f64(mat.xh).reshape(-1), _f64(mat.xhe).reshape(-1)
+        assert xh.size == 2 * self.ncell and xhe.size == 3 * self.ncell
+        tp = None
+        if mat.temperature_grid is not None:
+            t = np.ascontiguousarray(mat.temperature_grid, dtype=np.float32).reshape(-1)
+            assert t.size == 3 * self.ncell
+            tp = t.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self.lib.c2r_upload_state(self.h, _dp(xh), _dp(xhe), tp))
+
+    def download_state(self, mat: Material):
+        xh = np.empty(2 * self.ncell)
+        xhe = np.empty(3 * self.ncell)
+        t = None if mat.temperature_grid is None else np.empty(3 * self.ncell, dtype=np.float32)
+        tp = None if t is None else t.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(self.lib.c2r_download_state(self.h, _dp(xh), _dp(xhe), tp))
+        mat.xh, mat.xhe = xh, xhe
+        if t is not None:
+            mat.temperature_grid = t
+
+    # -- the pieces of evolve3D --------------------------------------------------------------
+    def begin_step(self):
+        self._chk(self.lib.c2r_begin_step(self.h))
+
+    def set_rates_to_zero(self):
+        self._chk(self.lib.c2r_set_rates_to_zero(self.h))
+
+    def pass_sources(self, first=1, stride=1):
+        self._chk(self.lib.c2r_pass_sources(self.h, int(first), int(stride)))
+
+    def global_pass(self, dt):
+        cf = C.c_int(0)
+        self._chk(self.lib.c2r_global_pass(self.h, float(dt), C.byref(cf)))
+        return cf.value
+
+    def end_step(self):
+        self._chk(self.lib.c2r_end_step(self.h))
+
+    def evolve3d(self, dt):
+        n = C.c_int(0)
+        flags = (C.c_int * 512)()
+        self._chk(self.lib.c2r_evolve3d(self.h, float(dt), C.byref(n), flags, 512))
+        return n.value, list(flags[: n.value])
+
+    def synchronize(self):
+        self._chk(self.lib.c2r_synchronize(self.h))
+
+    def set_batch(self, n):
+        self._chk(self.lib.c2r_set_batch(self.h, int(n)))
+
+    def enable_timing(self, on=True):
+        self._chk(self.lib.c2r_enable_timing(self.h, int(on)))
+
+    def timing(self):
+        t = _lib.Timing()
+        self._chk(self.lib.c2r_get_timing(self.h, C.byref(t)))
+        return t
+
+    # -- outputs -----------------------------------------------------------------------------
+    def download_rates(self):
+        n = self.ncell
+        phih, phihe, phiheat = np.empty(n), np.empty(2 * n), np.empty(n)
+        loss = np.empty(NFREQ)
+        nbox = C.c_int(0)
+        self._chk(self.lib.c2r_download_rates(self.h, _dp(phih), _dp(phihe), _dp(phiheat), _dp(loss), C.byref(nbox)))
+        return dict(phih_grid=phih, phihe_grid=phihe, phiheat=phiheat, photon_loss=loss, sum_nbox=nbox.value)
+
+    def download_iter_state(self):
+        n = self.ncell
+        a, b, c, d = np.empty(2 * n), np.empty(3 * n), np.empty(2 * n), np.empty(3 * n)
+        self._chk(self.lib.c2r_download_iter_state(self.h, _dp(a), _dp(b), _dp(c), _dp(d)))
+        return dict(xh_av=a, xhe_av=b, xh_intermed=c, xhe_intermed=d)
+
+    def upload_rates(self, phih=None, phihe=None, phiheat=None):
+        a = [None if x is None else _f64(x).reshape(-1) for x in (phih, phihe, phiheat)]
+        self._chk(self.lib.c2r_upload_rates(self.h, *[_dp(x) for x in a]))
+
+    def upload_iter_state(self, xh_av=None, xhe_av=None, xh_intermed=None, xhe_intermed=None):
+        a = [None if x is None else _f64(x).reshape(-1) for x in (xh_av, xhe_av, xh_intermed, xhe_intermed)]
+        self._chk(self.lib.c2r_upload_iter_state(self.h, *[_dp(x) for x in a]))
+
+    def download_columns(self):
+        n = self.ncell
+        a, b = np.empty(n), np.empty(2 * n)
+        self._chk(self.lib.c2r_download_columns(self.h, _dp(a), _dp(b)))
+        return dict(coldensh_out=a, coldenshe_out=b)
+
+    # -- reduction buffer ----------------------------------------------------------------------
+    def rates_count(self):
+        return int(self.lib.c2r_rates_count(self.h))
+
+    def rates_buffer(self):
+        if self._ext_rates is None:
+            raise C2RayHipError("no shared reduction buffer: call use_torch_rates_buffer(device) first")
+        return self._ext_rates
+
+    def rates_reduced(self):
+        return None
+
+    def use_torch_rates_buffer(self, device):
+        """Allocate the reduction buffer as a torch tensor so torch.distributed (RCCL) can
+        all-reduce it in place; returns the tensor."""
+        import torch
+        t = torch.zeros(self.rates_count(), dtype=torch.float64, device=device)
+        self._chk(self.lib.c2r_set_rates_buffer(self.h, C.c_void_p(t.data_ptr()), t.numel()))
+        self._ext_rates = t
+        return t
+
+
+class Evolve:
+    """module evolve + evolve_data: evolve_ini() == construction, evolve3D(time, dt, restart).
+
+    comm: optional object with .rank, .size and .allreduce_sum_(buffer) (see parallel.py) -- the
+    MPI analogue of the reference: sources are dealt round-robin over the ranks
+    (do_grid_static, master_slave.F90:74-96: `do ns1 = 1+rank, NumSrc, npr`), the rate grids are
+    summed over ranks (mpi_accumulate_grid_quantities, evolve.F90:505-548) and the global
+    chemistry pass is replicated on every rank (evolve.F90:477-484).
+    """
+
+    def __init__(self, mesh, tables: RadiationTables | None = None, device=0, engine=None, comm=None):
+        self.mesh = tuple(int(m) for m in mesh)
+        self.engine = engine if engine is not None else HipEngine(self.mesh, device)
+        self.tables = tables if tables is not None else RadiationTables.load()
+        self.engine.set_tables(self.tables)
+        self.comm = comm
+        if comm is not None and comm.size > 1 and isinstance(self.engine, HipEngine):
+            self.engine.use_torch_rates_buffer(f"cuda:{device}")
+        self.niter = 0
+        self.conv_flags: list[int] = []
+        self.sum_nbox_all = 0
+        self.photon_loss_all = np.zeros(NFREQ)
+
+    # subroutine evolve3D (time,dt,restart) -- evolve.F90:78
+    def evolve3D(self, time, dt, restart, material: Material, grid: GridProps, sources: SourceProps,
+                 cosmology: Cosmology | None = None):
+        if restart != 0:
+            raise NotImplementedError("restart from an iteration dump (evolve.F90:138-140) is not available yet")
+        cosmology = cosmology or Cosmology()
+        e = self.engine
+        e.set_step(material, grid, cosmology)
+        e.set_sources(sources)
+        e.upload_state(material)
+        if self.comm is None or self.comm.size == 1:
+            self.niter, self.conv_flags = e.evolve3d(dt)
+        else:
+            self._evolve3d_multi(dt, sources.NumSrc)
+        e.download_state(material)
+        r = e.download_rates()
+        self.sum_nbox_all = r["sum_nbox"]
+        self.photon_loss_all = r["photon_loss"]
+        return self.niter
+
+    def _evolve3d_multi(self, dt, numsrc):
+        e, comm = self.engine, self.comm
+        ncell = int(np.prod(self.mesh))
+        e.begin_step()
+        niter, conv_flag = 0, ncell
+        conv_criterion = min(int(convergence_fraction * self.mesh[0] * self.mesh[1] * self.mesh[2]), numsrc)
+        self.conv_flags = []
+        while True:
+            if conv_flag < conv_criterion and niter > 1:
+                e.end_step()
+                break
+            elif niter > 500:
+                break
+            niter += 1
+            e.set_rates_to_zero()
+            if numsrc > 0:
+                e.pass_sources(1 + comm.rank, comm.size)
+                comm.allreduce_rates(e)
+            conv_flag = e.global_pass(dt)
+            self.conv_flags.append(conv_flag)
+        self.niter = niter
+
+    # use evolve_data, only: phih_grid, phiheat (output.F90:26)
+    @property
+    def rates(self):
+        return self.engine.download_rates()
+
+    @property
+    def iter_state(self):
+        return self.engine.download_iter_state()

@@ -1,0 +1,137 @@
+/* C ABI of the MI355X (gfx950) implementation of C2-Ray's evolve3D hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference's
+ * code/ directory).  Host arrays are caller-owned contiguous Fortran arrays, i fastest,
+ * components slowest: xh(N1,N2,N3,0:1), xhe(N1,N2,N3,0:2), temperature_grid(N1,N2,N3,0:2) real(4).
+ * The library owns device memory only.  All calls return 0 on success; on failure they return a
+ * non-zero status and c2r_last_error() describes it (the reference has no error convention: its
+ * Fortran shim logs the text to unit logf and stops).
+ *
+ * Threading: one host thread per context; one context per GPU (one rank per GPU).
+ */
+#ifndef C2RAY_HIP_H
+#define C2RAY_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct c2r_ctx c2r_ctx;
+
+#define C2R_NFREQ 47  /* radiation_sizes.f90:22 NumFreqBnd */
+#define C2R_NHEAT 113 /* radiation_sizes.f90:23 NumheatBin */
+#define C2R_NTAU 2000 /* radiation_sizes.f90:18 NumTau */
+#define C2R_NCOOL 801 /* cooling_h.f90:25 temppoints */
+
+/* evolve_ini (files_for_3D/evolve_data.F90:74-97): allocate the work arrays, here on `device`.
+ * mesh = sizes.f90:31. */
+int c2r_create(c2r_ctx **out, int device, const int mesh[3]);
+void c2r_destroy(c2r_ctx *ctx);
+const char *c2r_last_error(const c2r_ctx *ctx);
+/* error text of a failed c2r_create (no context exists yet) */
+const char *c2r_create_error(void);
+
+/* What rad_ini leaves behind (radiation_tables.f90:141-168, radiation_sizes.f90:62-688):
+ * bb_photo_thick/thin_table(0:NumTau,1:NumFreqBnd), bb_heat_thick/thin_table(0:NumTau,1:NumheatBin)
+ * (tau index fastest; heat tables may be NULL for isothermal-only use), sigma_HI/HeI/HeII(1:47),
+ * the twelve secondary-ionisation vectors f1ion_HI .. f2heat_HeII, each (2:47) = 46 doubles, in the
+ * order f1ion_{HI,HeI,HeII}, f2ion_{..}, f1heat_{..}, f2heat_{..} (may be NULL with the heat tables),
+ * and bb_FreqBnd_UpperLimit (radiation_tables.f90:193-199). */
+int c2r_set_tables(c2r_ctx *ctx, const double *photo_thick, const double *photo_thin,
+                   const double *heat_thick, const double *heat_thin, const double *sigma_HI,
+                   const double *sigma_HeI, const double *sigma_HeII, const double *const fvec[12],
+                   int bb_upper);
+
+/* What setup_cool leaves behind (cooling_h.f90:76-171): five linear cooling curves of 801 points
+ * (H0, H1, He0, He1, He2), log10 T of the first row and the step. */
+int c2r_set_cooling(c2r_ctx *ctx, const double *cool5x801, double mintemp, double dtemp);
+
+/* Host state read at every evolve3D call because the driver rescales it each step
+ * (cosmology.f90:159-202): material:ndens, grid:dr,vol, material:clumping (real(4)), cosmology:zred,
+ * cosmology_parameters:H0,Omega0, material:isothermal,temper_val, and the twelve module-global
+ * coefficients of cgsconstants.f90:106-133 in the order arech0, brech0, areche0, breche0, oreche0,
+ * areche1, breche1, treche1, colli_HI, colli_HeI, colli_HeII, v (used as they stand when isothermal;
+ * re-evaluated per cell from the temperature otherwise, evolve_point.F90:543). */
+int c2r_set_step(c2r_ctx *ctx, const double *ndens, const double dr[3], double vol, float clumping,
+                 double zred, double H0, double Omega0, int isothermal, double temper_val,
+                 const double reccoef[12]);
+
+/* sourceprops: NumSrc, srcpos(3,NumSrc) (1-based mesh coordinates), NormFlux(1:NumSrc), and
+ * radiation_sed_parameters:S_star (sourceprops_test.F90:38-40). */
+int c2r_set_sources(c2r_ctx *ctx, int nsrc, const int *srcpos, const double *normflux, double s_star);
+
+/* material:xh, xhe, temperature_grid (temperature may be NULL when isothermal) */
+int c2r_upload_state(c2r_ctx *ctx, const double *xh, const double *xhe, const float *temperature);
+int c2r_download_state(c2r_ctx *ctx, double *xh, double *xhe, float *temperature);
+
+/* evolve3D(time,dt,restart) with restart == 0 (files_for_3D/evolve.F90:78-229): the whole
+ * convergence loop on the device.  niter_out: number of outer iterations; conv_flags_out (may be
+ * NULL, capacity cap): non-converged count after each global pass (evolve.F90:488). */
+int c2r_evolve3d(c2r_ctx *ctx, double dt, int *niter_out, int *conv_flags_out, int cap);
+
+/* The pieces of evolve3D, for hosts that drive the loop themselves (multi-rank runs reduce the
+ * rate grids between c2r_pass_sources and c2r_global_pass):
+ *   c2r_begin_step      evolve.F90:131-136  xh_av = xh_intermed = xh, xhe_* likewise
+ *   c2r_set_rates_to_zero evolve.F90:371-381
+ *   c2r_pass_sources    do_grid_static (master_slave.F90:74-96): do_source for ns = first,
+ *                       first+stride, ... <= NumSrc (1-based) -- evolve_source.F90:66-238
+ *   c2r_global_pass     evolve.F90:435-501 loop: evolve0D_global for every cell
+ *   c2r_end_step        evolve.F90:164-166  xh = xh_intermed, xhe = xhe_intermed,
+ *                       set_final_temperature_point */
+int c2r_begin_step(c2r_ctx *ctx);
+int c2r_set_rates_to_zero(c2r_ctx *ctx);
+int c2r_pass_sources(c2r_ctx *ctx, int first, int stride);
+int c2r_global_pass(c2r_ctx *ctx, double dt, int *conv_flag);
+int c2r_end_step(c2r_ctx *ctx);
+
+/* evolve_data: phih_grid, phihe_grid(:,:,:,0:1), phiheat; photonstatistics: photon_loss(1:47)
+ * (as summed over this rank's sources, i.e. photon_loss_all before the division by mesh^3 of
+ * evolve.F90:457); evolve_source: sum_nbox.  Any pointer may be NULL. */
+int c2r_download_rates(c2r_ctx *ctx, double *phih, double *phihe, double *phiheat,
+                       double *photon_loss47, int *sum_nbox);
+/* evolve_data: xh_av, xhe_av, xh_intermed, xhe_intermed -- the iteration-dump content
+ * (write_iteration_dump, evolve.F90:233-275). */
+int c2r_download_iter_state(c2r_ctx *ctx, double *xh_av, double *xhe_av, double *xh_intermed,
+                            double *xhe_intermed);
+/* start_from_dump (evolve.F90:279-367) reloads exactly these arrays before calling global_pass:
+ * phih_grid, phihe_grid, [phiheat], xh_av, xhe_av, xh_intermed, xhe_intermed.  Any pointer may be
+ * NULL (left as is). */
+int c2r_upload_rates(c2r_ctx *ctx, const double *phih, const double *phihe, const double *phiheat);
+int c2r_upload_iter_state(c2r_ctx *ctx, const double *xh_av, const double *xhe_av,
+                          const double *xh_intermed, const double *xhe_intermed);
+/* evolve_data: coldensh_out, coldenshe_out(:,:,:,0:1) of the source swept last (diagnostic). */
+int c2r_download_columns(c2r_ctx *ctx, double *coldensh_out, double *coldenshe_out);
+
+/* The buffer that mpi_accumulate_grid_quantities (evolve.F90:505-548) sums over ranks, as ONE
+ * contiguous device array of c2r_rates_count() doubles:
+ *   [ phih_grid | phihe_grid(0) | phihe_grid(1) | phiheat | photon_loss(1:47) | sum_nbox ]
+ * so that a single all-reduce(SUM, fp64) replaces the reference's four grid all-reduces and two
+ * small ones.  c2r_rates_device_ptr returns its device address (after c2r_synchronize the data is
+ * complete); c2r_set_rates_buffer makes the library use a caller-allocated device buffer instead
+ * (e.g. a torch tensor that torch.distributed/RCCL reduces in place). */
+size_t c2r_rates_count(const c2r_ctx *ctx);
+void *c2r_rates_device_ptr(c2r_ctx *ctx);
+int c2r_set_rates_buffer(c2r_ctx *ctx, void *device_ptr, size_t count);
+int c2r_synchronize(c2r_ctx *ctx);
+
+/* Sources swept concurrently by one batch of launches (device scratch = 6 grids per source). */
+int c2r_set_batch(c2r_ctx *ctx, int nbatch);
+
+/* Timing of the last c2r_pass_sources / c2r_global_pass on the context's stream, measured with
+ * HIP events on that stream: milliseconds spent in the column sweep launches, the rates kernel
+ * and the chemistry kernel, and the number of launches of each. */
+typedef struct {
+  double sweep_ms, rates_ms, chem_ms;
+  int sweep_launches, rates_launches, chem_launches;
+  long long cells_swept; /* cell x source pairs actually traced by the last c2r_pass_sources */
+} c2r_timing;
+int c2r_get_timing(c2r_ctx *ctx, c2r_timing *out);
+int c2r_enable_timing(c2r_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

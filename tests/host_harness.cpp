@@ -1,0 +1,138 @@
+// TEST-ONLY: compiles the product's device functions (c2-ray3dm1d_helium_amd/csrc/c2ray_device.hpp)
+// with the host C++ compiler so that the CPU test-suite can run them against the golden vectors
+// before the code ever reaches a GPU.  Nothing in the product links this file.
+//   g++ -O2 -ffp-contract=off -mfma -fPIC -shared -o _host_harness.so host_harness.cpp
+// (-mfma only so that __builtin_fma is one instruction; no expression is contracted)
+#include <cstddef>
+#include <cstring>
+#include <vector>
+
+#include "../c2-ray3dm1d_helium_amd/csrc/c2ray_device.hpp"
+
+using namespace c2r;
+
+namespace {
+struct Tables {
+  BandData bd;
+  std::vector<double> pthick, pthin, hthick, hthin, cool;
+  double mintemp, dtemp;
+};
+Tables T;
+
+void pitch(const double *src, int ncol, std::vector<double> &dst) {
+  dst.assign((size_t)ncol * NTAUP, 0.0);
+  for (int c = 0; c < ncol; c++) {
+    std::memcpy(&dst[(size_t)c * NTAUP], src + (size_t)c * (NTAU + 1), sizeof(double) * (NTAU + 1));
+    dst[(size_t)c * NTAUP + NTAU + 1] = src[(size_t)c * (NTAU + 1) + NTAU];
+  }
+}
+} // namespace
+
+extern "C" {
+
+void hh_set_tables(const double *pthick, const double *pthin, const double *hthick, const double *hthin,
+                   const double *sHI, const double *sHeI, const double *sHeII, const double *const f[12],
+                   int bb_upper, const double *cool, double mintemp, double dtemp) {
+  std::memset(&T.bd, 0, sizeof T.bd);
+  pitch(pthick, NFREQ, T.pthick);
+  pitch(pthin, NFREQ, T.pthin);
+  pitch(hthick, NHEAT, T.hthick);
+  pitch(hthin, NHEAT, T.hthin);
+  std::memcpy(T.bd.sigma_HI, sHI, sizeof T.bd.sigma_HI);
+  std::memcpy(T.bd.sigma_HeI, sHeI, sizeof T.bd.sigma_HeI);
+  std::memcpy(T.bd.sigma_HeII, sHeII, sizeof T.bd.sigma_HeII);
+  double *dst[12] = {T.bd.f1ion_HI, T.bd.f1ion_HeI, T.bd.f1ion_HeII, T.bd.f2ion_HI, T.bd.f2ion_HeI, T.bd.f2ion_HeII,
+                     T.bd.f1heat_HI, T.bd.f1heat_HeI, T.bd.f1heat_HeII, T.bd.f2heat_HI, T.bd.f2heat_HeI, T.bd.f2heat_HeII};
+  for (int i = 0; i < 12; i++) std::memcpy(dst[i], f[i], sizeof(double) * (NFREQ - 1));
+  T.bd.bb_upper = bb_upper;
+  T.cool.assign(cool, cool + 5 * NCOOL);
+  T.mintemp = mintemp;
+  T.dtemp = dtemp;
+}
+
+void hh_reccoef(double temperature, double *out12) {
+  RecCoef rc;
+  ini_rec_colion_factors(temperature, rc);
+  std::memcpy(out12, &rc, sizeof rc);
+}
+
+// out5 = photo_HI, photo_HeI, photo_HeII, heat, photo_out
+void hh_photoion(const double *cin6, double vol, double nflux, double i_state, int heat, double *out5) {
+  PhotoOut o;
+  if (heat)
+    photoion_rates<true>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick.data(), T.hthin.data(), cin6[0], cin6[1],
+                         cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, i_state, o);
+  else
+    photoion_rates<false>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick.data(), T.hthin.data(), cin6[0], cin6[1],
+                          cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, i_state, o);
+  out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
+}
+
+double hh_photo_out_only(const double *cin6, double nflux) {
+  return photo_out_only(T.bd, T.pthick.data(), T.pthin.data(), cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5],
+                        nflux);
+}
+
+void hh_doric(double dt, double de, double *ion15, const double *phi3, const double *fr4, const double *rc12,
+              double clumping) {
+  IonStates ion;
+  RecCoef rc;
+  std::memcpy(&ion, ion15, sizeof ion);
+  std::memcpy(&rc, rc12, sizeof rc);
+  doric(dt, de, ion, phi3[0], phi3[1], phi3[2], fr4[0], fr4[1], fr4[2], fr4[3], rc, clumping);
+  std::memcpy(ion15, &ion, sizeof ion);
+}
+
+void hh_prepare_doric_factors(double NH, double NHe0, double NHe1, double *out4) {
+  prepare_doric_factors(NH, NHe0, NHe1, out4[0], out4[1], out4[2], out4[3]);
+}
+
+void hh_thermal(double dt, double *tend, double *tavg, double de, double nd, const double *ion15, double heat,
+                double zred, double H0, double Omega0) {
+  IonStates ion;
+  std::memcpy(&ion, ion15, sizeof ion);
+  CoolData cd{T.cool.data(), T.mintemp, T.dtemp, zred, H0, Omega0};
+  thermal(cd, dt, *tend, *tavg, de, nd, ion, heat);
+}
+
+// cinterp (column_density.f90:28-345) assembled from short_characteristic + interp_column the way
+// k_sweep_shell does it; pos/srcpos are 1-based, pos may lie outside the mesh.
+void hh_cinterp(const int *mesh, const double *cH, const double *cHe, const int *pos, const int *src, double *out4) {
+  const int n1 = mesh[0], n2 = mesh[1], n3 = mesh[2];
+  const size_t nc = (size_t)n1 * n2 * n3;
+  ShortChar s4;
+  short_characteristic(src[0], src[1], src[2], pos[0] - src[0], pos[1] - src[1], pos[2] - src[2], s4);
+  size_t qc[4];
+  for (int c = 0; c < 4; c++) {
+    int i = ((src[0] - 1 + s4.ci[c]) % n1 + n1) % n1, j = ((src[1] - 1 + s4.cj[c]) % n2 + n2) % n2,
+        k = ((src[2] - 1 + s4.ck[c]) % n3 + n3) % n3;
+    qc[c] = (size_t)i + (size_t)n1 * ((size_t)j + (size_t)n2 * k);
+  }
+  out4[0] = interp_column(s4, cH[qc[0]], cH[qc[1]], cH[qc[2]], cH[qc[3]], sigma_HI_at_ion_freq);
+  out4[1] = interp_column(s4, cHe[qc[0]], cHe[qc[1]], cHe[qc[2]], cHe[qc[3]], sigma_HeI_at_ion_freq);
+  out4[2] = interp_column(s4, cHe[nc + qc[0]], cHe[nc + qc[1]], cHe[nc + qc[2]], cHe[nc + qc[3]], sigma_HeII_at_ion_freq);
+  out4[3] = s4.path;
+}
+
+// the restated libm (csrc/c2ray_math.hpp) on arrays: op 0 exp, 1 log10, 2 pow
+void hh_math(int op, int n, const double *x, const double *y, double *out) {
+  for (int i = 0; i < n; i++)
+    out[i] = op == 0 ? C2R_MATH_EXP(x[i]) : (op == 1 ? C2R_MATH_LOG10(x[i]) : C2R_MATH_POW(x[i], y[i]));
+}
+// the platform libm the reference links (glibc): same ops
+void hh_libm(int op, int n, const double *x, const double *y, double *out) {
+  for (int i = 0; i < n; i++) out[i] = op == 0 ? exp(x[i]) : (op == 1 ? log10(x[i]) : pow(x[i], y[i]));
+}
+
+int hh_constants(double *out, int n) {
+  const double c[] = {pi, abu_he, abu_c, (1.0 - abu_he) + 4.0 * abu_he, gamma1, hplanck, k_B, 1.672661e-24, temph0,
+                      temphe0, temphe1, colh0, colhe0, colhe1, ev2k, ev2fr, eth0, ethe0, ethe1, sigma_HI_at_ion_freq,
+                      sigma_HeI_at_ion_freq, sigma_HeII_at_ion_freq, ion_freq_HI, ion_freq_HeI, ev2fr * ethe1,
+                      sigma_H_heth, sigma_H_heLya, sigma_He_heLya, sigma_He_he2, sigma_H_he2, epsilon,
+                      convergence_fraction, minimum_fractional_change, minimum_fraction_of_atoms, minitemp,
+                      relative_denergy, minlogtau, dlogtau};
+  const int m = (int)(sizeof c / sizeof c[0]);
+  for (int i = 0; i < m && i < n; i++) out[i] = c[i];
+  return m;
+}
+}

@@ -1,0 +1,102 @@
+"""The product's device functions (csrc/c2ray_device.hpp) compiled for the host, against the
+reference's golden vectors and against the oracle.  On the host they use glibc's exp/log10/pow, the
+same libm the reference build links, so the comparison is bit-exact; on the GPU the same source is
+compiled by hipcc (tests/test_gpu_parity.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import tap_case
+
+dp = C.POINTER(C.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def hh(harness, pkg):
+    t = pkg.RadiationTables.load()
+    keep = [t.fvec[k] for k in pkg.evolve.FVEC_ORDER]
+    fv = (dp * 12)(*[_p(a) for a in keep])
+    harness.hh_set_tables(_p(t.photo_thick), _p(t.photo_thin), _p(t.heat_thick), _p(t.heat_thin), _p(t.sigma_HI),
+                          _p(t.sigma_HeI), _p(t.sigma_HeII), fv, C.c_int(t.bb_upper), _p(t.cool),
+                          C.c_double(t.cool_mintemp), C.c_double(t.cool_dtemp))
+    harness._keep = (t, keep)
+    return harness
+
+
+def test_constants(hh, gold):
+    ref = gold("consts.npz")["consts"]
+    buf = (C.c_double * 64)()
+    n = hh.hh_constants(buf, 64)
+    assert np.array_equal(np.array(buf[:n]), ref[:n])
+
+
+def test_reccoef(hh, gold):
+    a = gold("funcvec.npz")["reccoef_T"].reshape(-1, 13)
+    out = np.empty(12)
+    for row in a:
+        hh.hh_reccoef(C.c_double(row[0]), _p(out))
+        assert np.array_equal(out, row[1:])
+
+
+@pytest.mark.parametrize("key,heat", [("photoion_iso", 0), ("photoion_heat", 1)])
+def test_photoion(hh, gold, key, heat):
+    a = gold("funcvec.npz")[key].reshape(-1, 30)
+    out = np.empty(5)
+    for row in a:
+        cin = np.ascontiguousarray(row[:6])
+        hh.hh_photoion(_p(cin), C.c_double(row[6]), C.c_double(row[8]), C.c_double(row[7]), C.c_int(heat), _p(out))
+        ref = row[9:]
+        # photo_cell_HI, HeI, HeII, heat, photo_out = members 0,1,2,18,20 of type photrates
+        assert np.array_equal(out, ref[[0, 1, 2, 18, 20]])
+        assert hh.hh_photo_out_only(_p(cin), C.c_double(row[8])) == ref[20]
+
+
+def test_doric(hh, gold):
+    a = gold("funcvec.npz")["doric"].reshape(-1, 54)
+    for row in a:
+        ion = np.ascontiguousarray(row[20:35]).copy()
+        hh.hh_doric(C.c_double(row[0]), C.c_double(row[1]), _p(ion), _p(np.ascontiguousarray(row[4:7])),
+                    _p(np.ascontiguousarray(row[35:39])), _p(np.ascontiguousarray(row[7:19])), C.c_double(row[3]))
+        assert np.array_equal(ion, row[39:54])
+
+
+def test_thermal(hh, gold):
+    a = gold("funcvec.npz")["thermal"].reshape(-1, 25)
+    c = gold("consts.npz")["consts"]
+    for row in a:
+        te, ta = C.c_double(row[1]), C.c_double(-1.0)
+        hh.hh_thermal(C.c_double(row[0]), C.byref(te), C.byref(ta), C.c_double(row[2]), C.c_double(row[3]),
+                      _p(np.ascontiguousarray(row[6:21])), C.c_double(row[4]), C.c_double(row[5]), C.c_double(c[42]),
+                      C.c_double(c[43]))
+        assert te.value == row[21] and ta.value == row[22]
+
+
+def test_cinterp_equals_oracle_everywhere(hh, orc, gold):
+    """short_characteristic + interp_column (what the sweep kernel runs) against the oracle's
+    cinterp for EVERY offset of a 16^3 and a 22^3 box, on the reference's own column grids."""
+    for fname in ["tap_N16_heat_3src.npz", "tap_N22_iso_2src.npz"]:
+        i, o = tap_case(gold(fname), 1)
+        mesh = np.ascontiguousarray(i["mesh"], dtype=np.int32)
+        n = int(mesh[0])
+        cH, cHe = np.ascontiguousarray(o["coldensh_out"]), np.ascontiguousarray(o["coldenshe_out"])
+        src = np.ascontiguousarray(i["srcpos"].reshape(-1, 3)[-1], dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        out = np.empty(4)
+        lo, hi = -(n // 2), n - n // 2 - 1
+        for dk in range(lo, hi + 1):
+            for dj in range(lo, hi + 1):
+                for di in range(lo, hi + 1):
+                    if di == 0 and dj == 0 and dk == 0:
+                        continue
+                    pos = np.array([src[0] + di, src[1] + dj, src[2] + dk], dtype=np.int32)
+                    hh.hh_cinterp(mesh.ctypes.data_as(ip), _p(cH), _p(cHe), pos.ctypes.data_as(ip),
+                                  src.ctypes.data_as(ip), _p(out))
+                    a, b, c, d = (C.c_double(), C.c_double(), C.c_double(), C.c_double())
+                    orc.lib().orc_cinterp(mesh.ctypes.data_as(ip), _p(cH), _p(cHe), pos.ctypes.data_as(ip),
+                                          src.ctypes.data_as(ip), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+                    assert (out[0], out[1], out[2], out[3]) == (a.value, b.value, c.value, d.value), (di, dj, dk)

@@ -1,0 +1,78 @@
+"""The oracle (oracle/c2ray_oracle.c) against vectors produced by the reference itself.
+
+Everything here is bit-exact: the oracle restates the reference operation by operation and the
+reference was built without FMA contraction (flang -O2, x86-64)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err, tap_case
+
+
+def test_constants_match_reference_build(orc, gold):
+    ref = gold("consts.npz")["consts"]
+    mine = orc.constants()
+    assert np.array_equal(mine, ref[: len(mine)])
+
+
+def test_ini_rec_colion_factors(orc, gold):
+    a = gold("funcvec.npz")["reccoef_T"].reshape(-1, 13)
+    for row in a:
+        assert np.array_equal(orc.ini_rec_colion_factors(row[0]), row[1:]), row[0]
+
+
+@pytest.mark.parametrize("key,iso", [("photoion_iso", 1), ("photoion_heat", 0)])
+def test_photoion_rates(orc, otables, gold, key, iso):
+    a = gold("funcvec.npz")[key].reshape(-1, 30)
+    for row in a:
+        got = orc.photoion_rates(otables, row[:6], row[6], row[8], row[7], iso)
+        assert np.array_equal(got, row[9:])
+
+
+def test_doric(orc, gold):
+    a = gold("funcvec.npz")["doric"].reshape(-1, 54)
+    for row in a:
+        got = orc.doric(row[0], row[1], row[2], row[20:35], row[4:7], row[35:39], row[7:19], row[3])
+        assert np.array_equal(got, row[39:54])
+
+
+def test_thermal(orc, otables, gold):
+    a = gold("funcvec.npz")["thermal"].reshape(-1, 25)
+    c = gold("consts.npz")["consts"]
+    for row in a:
+        te, ta = orc.thermal(otables, row[0], row[1], -1.0, row[2], row[3], row[6:21], row[4], row[5], c[42], c[43])
+        assert te == row[21] and ta == row[22]
+
+
+CASES = [("tap_N16_iso_1src.npz", 1), ("tap_N16_iso_1src.npz", 2), ("tap_N16_heat_3src.npz", 1),
+         ("tap_N16_heat_3src.npz", 2), ("tap_N22_iso_2src.npz", 1)]
+
+
+@pytest.mark.parametrize("fname,call", CASES)
+def test_evolve3d_end_to_end(orc, otables, gold, fname, call):
+    """Whole evolve3D calls: same iteration count, same non-converged counts per iteration, and
+    every output array bit-identical to what the reference wrote."""
+    i, o = tap_case(gold(fname), call)
+    st = orc.Step.from_tap(i)
+    s = orc.State(st, i["xh"], i["xhe"], i.get("temperature"))
+    nit = orc.evolve3d(otables, st, s, i["dt"][0])
+    assert nit == len(o["conv_flags"])
+    assert s.conv_flags == list(o["conv_flags"])
+    names = {"xh": "xh", "xhe": "xhe", "phih_grid": "phih", "phihe_grid": "phihe", "xh_av": "xh_av",
+             "xhe_av": "xhe_av", "xh_intermed": "xh_intermed", "xhe_intermed": "xhe_intermed",
+             "coldensh_out": "coldensh_out", "coldenshe_out": "coldenshe_out", "photon_loss_all": "photon_loss"}
+    if not st.isothermal:
+        names.update(temperature="temperature", phiheat="phiheat")
+    for k, attr in names.items():
+        assert np.array_equal(getattr(s, attr), o[k]), k
+    assert s.c.sum_nbox == o["sum_nbox_all"][0]
+
+
+def test_n22_far_layer_never_traced(orc, otables, gold):
+    """(N/2-1) mod 10 == 0: the while-test of evolve_source.F90:136-139 stops after box 1 and the
+    layer at offset -N/2 gets no column."""
+    i, o = tap_case(gold("tap_N22_iso_2src.npz"), 1)
+    col = o["coldensh_out"].reshape(22, 22, 22, order="F")
+    src = i["srcpos"].reshape(-1, 3)[-1]  # columns are those of the source swept last
+    far = (src - 1 - 11) % 22
+    assert np.all(col[far[0], :, :] == 0.0) and np.all(col[:, far[1], :] == 0.0) and np.all(col[:, :, far[2]] == 0.0)
+    assert np.count_nonzero(col) == 21 ** 3
