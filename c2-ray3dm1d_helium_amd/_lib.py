@@ -44,6 +44,7 @@ SYMBOLS = {
     "c2r_begin_step": (C.c_int, [C.c_void_p]),
     "c2r_set_rates_to_zero": (C.c_int, [C.c_void_p]),
     "c2r_pass_sources": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "c2r_do_source": (C.c_int, [C.c_void_p, C.c_int]),
     "c2r_global_pass": (C.c_int, [C.c_void_p, C.c_double, _ip]),
     "c2r_end_step": (C.c_int, [C.c_void_p]),
     "c2r_download_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),

@@ -717,10 +717,8 @@ static int box_smax(const SrcRun &r) {
   return m;
 }
 
-extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
-  if (!c) return 1;
-  if (check_ready(c, "c2r_pass_sources")) return 1;
-  if (first < 1 || stride < 1) return fail(c, "c2r_pass_sources: first=%d stride=%d", first, stride);
+// do_source (evolve_source.F90:66-238) for every source number in `mine`, `batch` at a time
+static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
   HIPCHK(c, hipSetDevice(c->device));
   if (alloc_col(c)) return 1;
   const Grid g = c->g;
@@ -730,9 +728,6 @@ extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
   c->tm.sweep_ms = c->tm.rates_ms = 0.0;
   c->tm.sweep_launches = c->tm.rates_launches = 0;
   c->tm.cells_swept = 0;
-
-  std::vector<int> mine;
-  for (int ns = first; ns <= c->nsrc; ns += stride) mine.push_back(ns);
 
   for (size_t b0 = 0; b0 < mine.size(); b0 += c->batch) {
     const int nb = (int)std::min<size_t>(c->batch, mine.size() - b0);
@@ -868,6 +863,22 @@ extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
   HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * nc, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
+}
+
+extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
+  if (!c) return 1;
+  if (check_ready(c, "c2r_pass_sources")) return 1;
+  if (first < 1 || stride < 1) return fail(c, "c2r_pass_sources: first=%d stride=%d", first, stride);
+  std::vector<int> mine;
+  for (int ns = first; ns <= c->nsrc; ns += stride) mine.push_back(ns);
+  return pass_list(c, mine);
+}
+
+extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
+  if (!c) return 1;
+  if (check_ready(c, "c2r_do_source")) return 1;
+  if (ns < 1 || ns > c->nsrc) return fail(c, "c2r_do_source: source %d not in [1,%d]", ns, c->nsrc);
+  return pass_list(c, std::vector<int>{ns});
 }
 
 extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {

@@ -197,6 +197,9 @@ class HipEngine:
     def pass_sources(self, first=1, stride=1):
         self._chk(self.lib.c2r_pass_sources(self.h, int(first), int(stride)))
 
+    def do_source(self, ns):
+        self._chk(self.lib.c2r_do_source(self.h, int(ns)))
+
     def global_pass(self, dt):
         cf = C.c_int(0)
         self._chk(self.lib.c2r_global_pass(self.h, float(dt), C.byref(cf)))

@@ -1,0 +1,243 @@
+!> iso_c_binding view of include/c2ray_hip.h -- the only place where the Fortran host meets C.
+!! Every interface below binds one entry point of the C ABI; argument order and meaning are those
+!! of the header.  Arrays are passed by address (assumed-size dummies), scalars by value.
+module c2ray_hip
+
+  use, intrinsic :: iso_c_binding
+
+  implicit none
+
+  public
+
+  !> c2r_timing of include/c2ray_hip.h
+  type, bind(C) :: c2r_timing
+     real(c_double) :: sweep_ms, rates_ms, chem_ms
+     integer(c_int) :: sweep_launches, rates_launches, chem_launches
+     integer(c_long_long) :: cells_swept
+  end type c2r_timing
+
+  interface
+
+     integer(c_int) function c2r_create(ctx, device, mesh) bind(C, name="c2r_create")
+       import :: c_int, c_ptr
+       type(c_ptr), intent(out) :: ctx
+       integer(c_int), value :: device
+       integer(c_int), intent(in) :: mesh(3)
+     end function c2r_create
+
+     subroutine c2r_destroy(ctx) bind(C, name="c2r_destroy")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end subroutine c2r_destroy
+
+     type(c_ptr) function c2r_last_error(ctx) bind(C, name="c2r_last_error")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_last_error
+
+     type(c_ptr) function c2r_create_error() bind(C, name="c2r_create_error")
+       import :: c_ptr
+     end function c2r_create_error
+
+     integer(c_int) function c2r_set_tables(ctx, photo_thick, photo_thin, heat_thick, heat_thin, &
+          sigma_HI, sigma_HeI, sigma_HeII, fvec, bb_upper) bind(C, name="c2r_set_tables")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: photo_thick(*), photo_thin(*)
+       type(c_ptr), value :: heat_thick, heat_thin   ! c_loc of the tables, or c_null_ptr
+       real(c_double), intent(in) :: sigma_HI(*), sigma_HeI(*), sigma_HeII(*)
+       type(c_ptr), intent(in) :: fvec(12)           ! c_loc of the twelve f vectors
+       integer(c_int), value :: bb_upper
+     end function c2r_set_tables
+
+     integer(c_int) function c2r_set_cooling(ctx, cool, mintemp, dtemp) bind(C, name="c2r_set_cooling")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: cool(*)
+       real(c_double), value :: mintemp, dtemp
+     end function c2r_set_cooling
+
+     integer(c_int) function c2r_set_step(ctx, ndens, dr, vol, clumping, zred, H0, Omega0, &
+          isothermal, temper_val, reccoef) bind(C, name="c2r_set_step")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: ndens(*), dr(3)
+       real(c_double), value :: vol
+       real(c_float), value :: clumping
+       real(c_double), value :: zred, H0, Omega0
+       integer(c_int), value :: isothermal
+       real(c_double), value :: temper_val
+       real(c_double), intent(in) :: reccoef(12)
+     end function c2r_set_step
+
+     integer(c_int) function c2r_set_sources(ctx, nsrc, srcpos, normflux, s_star) &
+          bind(C, name="c2r_set_sources")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nsrc
+       integer(c_int), intent(in) :: srcpos(*)
+       real(c_double), intent(in) :: normflux(*)
+       real(c_double), value :: s_star
+     end function c2r_set_sources
+
+     integer(c_int) function c2r_upload_state(ctx, xh, xhe, temperature) bind(C, name="c2r_upload_state")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: xh(*), xhe(*)
+       type(c_ptr), value :: temperature            ! c_loc(temperature_grid) or c_null_ptr
+     end function c2r_upload_state
+
+     integer(c_int) function c2r_download_state(ctx, xh, xhe, temperature) bind(C, name="c2r_download_state")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: xh(*), xhe(*)
+       type(c_ptr), value :: temperature
+     end function c2r_download_state
+
+     integer(c_int) function c2r_evolve3d(ctx, dt, niter, conv_flags, cap) bind(C, name="c2r_evolve3d")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int), intent(out) :: niter
+       integer(c_int), intent(out) :: conv_flags(*)
+       integer(c_int), value :: cap
+     end function c2r_evolve3d
+
+     integer(c_int) function c2r_begin_step(ctx) bind(C, name="c2r_begin_step")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_begin_step
+
+     integer(c_int) function c2r_set_rates_to_zero(ctx) bind(C, name="c2r_set_rates_to_zero")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_set_rates_to_zero
+
+     integer(c_int) function c2r_pass_sources(ctx, first, stride) bind(C, name="c2r_pass_sources")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: first, stride
+     end function c2r_pass_sources
+
+     integer(c_int) function c2r_do_source(ctx, ns) bind(C, name="c2r_do_source")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ns
+     end function c2r_do_source
+
+     integer(c_int) function c2r_global_pass(ctx, dt, conv_flag) bind(C, name="c2r_global_pass")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int), intent(out) :: conv_flag
+     end function c2r_global_pass
+
+     integer(c_int) function c2r_end_step(ctx) bind(C, name="c2r_end_step")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_end_step
+
+     integer(c_int) function c2r_download_rates(ctx, phih, phihe, phiheat, photon_loss, sum_nbox) &
+          bind(C, name="c2r_download_rates")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: phih(*), phihe(*), phiheat(*), photon_loss(*)
+       integer(c_int), intent(out) :: sum_nbox
+     end function c2r_download_rates
+
+     integer(c_int) function c2r_download_iter_state(ctx, xh_av, xhe_av, xh_intermed, xhe_intermed) &
+          bind(C, name="c2r_download_iter_state")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: xh_av(*), xhe_av(*), xh_intermed(*), xhe_intermed(*)
+     end function c2r_download_iter_state
+
+     integer(c_int) function c2r_upload_rates(ctx, phih, phihe, phiheat) bind(C, name="c2r_upload_rates")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: phih(*), phihe(*), phiheat(*)
+     end function c2r_upload_rates
+
+     integer(c_int) function c2r_upload_iter_state(ctx, xh_av, xhe_av, xh_intermed, xhe_intermed) &
+          bind(C, name="c2r_upload_iter_state")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: xh_av(*), xhe_av(*), xh_intermed(*), xhe_intermed(*)
+     end function c2r_upload_iter_state
+
+     integer(c_int) function c2r_download_columns(ctx, coldensh_out, coldenshe_out) &
+          bind(C, name="c2r_download_columns")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: coldensh_out(*), coldenshe_out(*)
+     end function c2r_download_columns
+
+     integer(c_size_t) function c2r_rates_count(ctx) bind(C, name="c2r_rates_count")
+       import :: c_size_t, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_rates_count
+
+     type(c_ptr) function c2r_rates_device_ptr(ctx) bind(C, name="c2r_rates_device_ptr")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_rates_device_ptr
+
+     integer(c_int) function c2r_set_rates_buffer(ctx, device_ptr, count) bind(C, name="c2r_set_rates_buffer")
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx, device_ptr
+       integer(c_size_t), value :: count
+     end function c2r_set_rates_buffer
+
+     integer(c_int) function c2r_synchronize(ctx) bind(C, name="c2r_synchronize")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_synchronize
+
+     integer(c_int) function c2r_set_batch(ctx, nbatch) bind(C, name="c2r_set_batch")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nbatch
+     end function c2r_set_batch
+
+     integer(c_int) function c2r_enable_timing(ctx, on) bind(C, name="c2r_enable_timing")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function c2r_enable_timing
+
+     integer(c_int) function c2r_get_timing(ctx, tm) bind(C, name="c2r_get_timing")
+       import :: c_int, c_ptr, c2r_timing
+       type(c_ptr), value :: ctx
+       type(c2r_timing), intent(out) :: tm
+     end function c2r_get_timing
+
+  end interface
+
+contains
+
+  !> Text of the last error of a context (or of a failed c2r_create when ctx is null)
+  function c2r_error_text(ctx) result(text)
+    type(c_ptr), intent(in) :: ctx
+    character(len=:), allocatable :: text
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: n
+
+    if (c_associated(ctx)) then
+       p = c2r_last_error(ctx)
+    else
+       p = c2r_create_error()
+    endif
+    text = ""
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, (/ 512 /))
+    n = 0
+    do while (n < 512)
+       if (s(n+1) == c_null_char) exit
+       n = n + 1
+    enddo
+    allocate(character(len=n) :: text)
+    if (n > 0) text = transfer(s(1:n), text)
+  end function c2r_error_text
+
+end module c2ray_hip

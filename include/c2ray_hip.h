@@ -84,6 +84,9 @@ int c2r_evolve3d(c2r_ctx *ctx, double dt, int *niter_out, int *conv_flags_out, i
 int c2r_begin_step(c2r_ctx *ctx);
 int c2r_set_rates_to_zero(c2r_ctx *ctx);
 int c2r_pass_sources(c2r_ctx *ctx, int first, int stride);
+/* do_source(dt,ns1,niter) (evolve_source.F90:66-238) for the single source ns1 (1-based): trace it
+ * and add its contribution to the rate grids, photon_loss(1) and sum_nbox. */
+int c2r_do_source(c2r_ctx *ctx, int ns);
 int c2r_global_pass(c2r_ctx *ctx, double dt, int *conv_flag);
 int c2r_end_step(c2r_ctx *ctx);
 

@@ -227,6 +227,11 @@ def do_source(tables, step, state, ns):
     return nbox, loss.value
 
 
+def do_source_accumulate(tables, step, state, ns):
+    """do_source + the bookkeeping of evolve_source.F90:233-236; the caller sums loss and nbox."""
+    return do_source(tables, step, state, ns)
+
+
 def ini_rec_colion_factors(T):
     rc = RecCoef()
     lib().orc_ini_rec_colion_factors(C.c_double(T), C.byref(rc))
