@@ -33,7 +33,9 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), *HIPCC_FLAGS, "-o", str(LIB), *map(str, SOURCES)]
+    # C2R_EXTRA_HIPCC_FLAGS: timing-only ablation builds (-DC2R_ABL_*), never for results
+    extra = os.environ.get("C2R_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-o", str(LIB), *map(str, SOURCES)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -28,6 +28,7 @@
 #else
 #define C2R_MATH_EXP(x) exp(x)
 #define C2R_MATH_LOG10(x) log10(x)
+#define C2R_MATH_LOG10P(x) log10(x)
 #define C2R_MATH_POW(x, y) pow(x, y)
 #endif
 
@@ -113,6 +114,41 @@ struct BandData {
 
 C2R_HD double dmax(double a, double b) { return a > b ? a : b; }
 C2R_HD double dmin(double a, double b) { return a < b ? a : b; }
+
+// ----------------------------------------------------------------------------------------
+// Correctly rounded a/b for a divisor used many times (the shell volume `vol`, the table step
+// `dlogtau`): with y = RN(1/b), q = RN(a*y), r = a - b*q (exact, one fma), the result
+// RN(q + r*y) IS RN(a/b) -- Markstein's theorem (P. Markstein, IBM J. Res. Dev. 34, 1990; Muller et
+// al., Handbook of Floating-Point Arithmetic, ch. "division with an fma") -- provided the
+// significand of b is not all ones and nothing under/overflows.  Both provisos are checked, with
+// the plain division as the fall-back, so the value is identical to the reference's `a/b` always.
+// tests/test_math_host.py checks 2e7 random operands; 8e8 were run once (0 mismatches).
+// 3 FP64 instructions instead of the ~12 (one quarter-rate) of the gfx950 division sequence.
+struct Recip {
+  double b, y;
+  bool ok;
+};
+C2R_HD Recip make_recip(double b) {
+  Recip R;
+  R.b = b;
+  R.y = 1.0 / b;
+  const uint64_t u = __builtin_bit_cast(uint64_t, b);
+  const int e = (int)((u >> 52) & 0x7ff);
+  R.ok = (u & 0x000FFFFFFFFFFFFFULL) != 0x000FFFFFFFFFFFFFULL && e > 1023 - 400 && e < 1023 + 400;
+  return R;
+}
+C2R_HD double div_recip(double a, const Recip &R) {
+#ifdef C2R_ABL_DIVVOL // timing-only ablation (wrong results): what do the corrected divisions cost?
+  return a * R.y;
+#endif
+  const double aa = fabs(a);
+  if (R.ok && ((aa > 0x1p-500 && aa < 0x1p500) || a == 0.0)) {
+    const double q = a * R.y;
+    const double r = __builtin_fma(-R.b, q, a);
+    return __builtin_fma(r, R.y, q);
+  }
+  return a / R.b;
+}
 
 // ----------------------------------------------------------------------------------------
 // cgsconstants.f90:140-266  ini_rec_colion_factors
@@ -287,7 +323,7 @@ C2R_HD void doric(double dt, double rhe, IonStates &ion, double phi_HI, double p
 // cooling_h.f90:40-71; cool = 5 x 801 linear curves (h0, h1, he0, he1, he2)
 C2R_HD double coolin(const double *cool, double mintemp, double dtemp, double nucldens, double eldens,
                      const double *xh, const double *xhe, double temp0) {
-  double tpos = (C2R_MATH_LOG10(temp0) - mintemp) / dtemp + 1.0;
+  double tpos = (C2R_MATH_LOG10P(temp0) - mintemp) / dtemp + 1.0;
   int itpos = (int)tpos;
   itpos = itpos < 1 ? 1 : itpos;
   itpos = itpos > NCOOL - 1 ? NCOOL - 1 : itpos;
@@ -360,8 +396,18 @@ struct TauPos {
   double residual;
 };
 C2R_HD TauPos tau_table_position(double tau) {
-  double lt = C2R_MATH_LOG10(dmax(1.0e-20, tau));
-  double odpos = dmin((double)NTAU, dmax(0.0, 1.0 + (lt - minlogtau) / dlogtau));
+#ifdef C2R_ABL_LOG // timing-only ablation (wrong results): what does log10 cost?
+  double lt = dmax(1.0e-20, tau) * 1.0e-3 - 3.0;
+#else
+  double lt = C2R_MATH_LOG10P(dmax(1.0e-20, tau));
+#endif
+  // (lt - minlogtau)/dlogtau, correctly rounded through the constant's reciprocal (div_recip);
+  // the numerator lies in [0, 24.5], dlogtau = 0x1.89374bc6a7efap-7
+  const double num = lt - minlogtau;
+  const double rdl = 1.0 / dlogtau;
+  const double q0 = num * rdl;
+  const double quo = __builtin_fma(__builtin_fma(-dlogtau, q0, num), rdl, q0);
+  double odpos = dmin((double)NTAU, dmax(0.0, 1.0 + quo));
   TauPos p;
   p.ipos = (int)odpos;
   p.residual = odpos - (double)p.ipos;
@@ -370,6 +416,9 @@ C2R_HD TauPos tau_table_position(double tau) {
 // :310-326; col points at row 0 of a column with pitch NTAUP whose row 2001 duplicates row 2000,
 // so that ipos_p1 = min(NumTau, ipos+1) needs no clamp: (c[2001]-c[2000])*residual == 0 exactly.
 C2R_HD double read_table(const double *col, const TauPos &p) {
+#ifdef C2R_ABL_TABLE // timing-only ablation (wrong results): what do the table gathers cost?
+  return p.residual + (double)p.ipos;
+#endif
   double a = col[p.ipos], b = col[p.ipos + 1];
   return a + (b - a) * p.residual;
 }
@@ -393,6 +442,7 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
   o.heat = 0.0;
   o.photo_out = 0.0;
   if (!(NFlux > 0.0)) return;
+  const Recip rvol = make_recip(vol);
   const double cell_HI = cout_HI - cin_HI;
   const double cell_HeI = cout_HeI - cin_HeI;
   const double cell_HeII = cout_HeII - cin_HeII;
@@ -428,11 +478,19 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
     // species split of this band (scale_int2 / scale_int3)
     double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
     if (b >= NB1 && b < NB1 + NB2) {
+#ifdef C2R_ABL_SCALE // timing-only ablation (wrong results)
+      double forscaleing = (sHI * cell_HI + sHeI * cell_HeI);
+#else
       double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI);
+#endif
       sc_HI = sHI * cell_HI * forscaleing;
       sc_HeI = sHeI * cell_HeI * forscaleing;
     } else if (b >= NB1 + NB2) {
+#ifdef C2R_ABL_SCALE
+      double forscaleing = (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
+#else
       double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
+#endif
       sc_HI = cell_HI * sHI * forscaleing;
       sc_HeI = cell_HeI * sHeI * forscaleing;
       sc_HeII = cell_HeII * sHeII * forscaleing;
@@ -452,14 +510,14 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
       }
       o.photo_out = o.photo_out + phi_out;
       if (b < NB1) {
-        o.photo_HI = o.photo_HI + phi_all / vol;
+        o.photo_HI = o.photo_HI + div_recip(phi_all, rvol);
       } else if (b < NB1 + NB2) {
-        o.photo_HI = o.photo_HI + sc_HI * phi_all / vol;
-        o.photo_HeI = o.photo_HeI + sc_HeI * phi_all / vol;
+        o.photo_HI = o.photo_HI + div_recip(sc_HI * phi_all, rvol);
+        o.photo_HeI = o.photo_HeI + div_recip(sc_HeI * phi_all, rvol);
       } else {
-        o.photo_HI = o.photo_HI + sc_HI * phi_all / vol;
-        o.photo_HeI = o.photo_HeI + sc_HeI * phi_all / vol;
-        o.photo_HeII = o.photo_HeII + sc_HeII * phi_all / vol;
+        o.photo_HI = o.photo_HI + div_recip(sc_HI * phi_all, rvol);
+        o.photo_HeI = o.photo_HeI + div_recip(sc_HeI * phi_all, rvol);
+        o.photo_HeII = o.photo_HeII + div_recip(sc_HeII * phi_all, rvol);
       }
     }
 
@@ -471,10 +529,10 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
         double h_HI;
         if (hthick) {
           double out_HI = NFlux * read_table(tk, pout);
-          h_HI = (in_HI - out_HI) / vol;
+          h_HI = div_recip(in_HI - out_HI, rvol);
         } else {
           h_HI = NFlux * (cell_HI * sHI) * read_table(heat_thin + (size_t)b * NTAUP, pin);
-          h_HI = h_HI / vol;
+          h_HI = div_recip(h_HI, rvol);
         }
         df_heat = h_HI;
       } else if (b < NB1 + NB2) {
@@ -485,15 +543,15 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
         double h_HI, h_HeI;
         if (hthick) {
           double out_HI = NFlux * read_table(tkH, pout);
-          h_HI = sc_HI * (in_HI - out_HI) / vol;
+          h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
           double out_HeI = NFlux * read_table(tkHe, pout);
-          h_HeI = sc_HeI * (in_HeI - out_HeI) / vol;
+          h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
         } else {
           const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
           h_HI = NFlux * (cell_HI * sHI) * read_table(tnH, pin);
-          h_HI = h_HI / vol;
+          h_HI = div_recip(h_HI, rvol);
           h_HeI = NFlux * (cell_HeI * sHeI) * read_table(tnHe, pin);
-          h_HeI = h_HeI / vol;
+          h_HeI = div_recip(h_HeI, rvol);
         }
         df_heat = h_HI + h_HeI;
         const int q = b - 1; // f arrays are dimension(2:47)
@@ -513,19 +571,19 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
         double h_HI, h_HeI, h_HeII;
         if (hthick) {
           double out_HI = NFlux * read_table(tkH, pout);
-          h_HI = sc_HI * (in_HI - out_HI) / vol;
+          h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
           double out_HeI = NFlux * read_table(tkHe, pout);
-          h_HeI = sc_HeI * (in_HeI - out_HeI) / vol;
+          h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
           double out_HeII = NFlux * read_table(tkHe2, pout);
-          h_HeII = sc_HeII * (in_HeII - out_HeII) / vol;
+          h_HeII = div_recip(sc_HeII * (in_HeII - out_HeII), rvol);
         } else {
           const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
           h_HI = NFlux * (cell_HI * sHI) * read_table(tnH, pin);
-          h_HI = h_HI / vol;
+          h_HI = div_recip(h_HI, rvol);
           h_HeI = NFlux * (cell_HeI * sHeI) * read_table(tnHe, pin);
-          h_HeI = h_HeI / vol;
+          h_HeI = div_recip(h_HeI, rvol);
           h_HeII = NFlux * (cell_HeII * sHeII) * read_table(tnHe2, pin);
-          h_HeII = h_HeII / vol;
+          h_HeII = div_recip(h_HeII, rvol);
         }
         df_heat = h_HI + h_HeI + h_HeII;
         const int q = b - 1;
@@ -551,7 +609,9 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
 }
 
 // photo_out only (the quantity evolve0D adds to the photon loss of boundary cells,
-// evolve_point.F90:310-315): same band loop as photo_lookuptable, nothing else.
+// evolve_point.F90:310-315): the band loop of photo_lookuptable reduced to phi_photo_out_all.
+// An optically thick band needs only the table position of tau_out (phi_out = NFlux*T(tau_out));
+// a thin one only that of tau_in (phi_out = phi_in - NFlux*dtau*Tthin(tau_in)): one log10 per band.
 C2R_HD double photo_out_only(const BandData &bd, const double *photo_thick, const double *photo_thin,
                              double cin_HI, double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII,
                              double cout_HeII, double NFlux) {
@@ -562,14 +622,14 @@ C2R_HD double photo_out_only(const BandData &bd, const double *photo_thick, cons
     const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
     const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
     const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
-    const TauPos pin = tau_table_position(tau_in);
     const double *tk = photo_thick + (size_t)b * NTAUP;
-    double phi_in = NFlux * read_table(tk, pin);
     double phi_out;
     if (fabs(tau_out - tau_in) > tau_photo_limit) {
       const TauPos pout = tau_table_position(tau_out);
       phi_out = NFlux * read_table(tk, pout);
     } else {
+      const TauPos pin = tau_table_position(tau_in);
+      double phi_in = NFlux * read_table(tk, pin);
       double phi_all = NFlux * (tau_out - tau_in) * read_table(photo_thin + (size_t)b * NTAUP, pin);
       phi_out = phi_in - phi_all;
     }

@@ -33,6 +33,8 @@ struct Grid {
   int n1, n2, n3;
   int l1, l2, l3; // left extent mesh/2 (evolve_source.F90:105)
   size_t ncell;
+  size_t colsize; // entries of one shell-ordered column array: (2*smax+1)^3
+  int smax;       // largest L-infinity shell index, max(l1,l2,l3)
 };
 
 struct SrcInfo {
@@ -68,6 +70,11 @@ __device__ __forceinline__ size_t cell_index(const Grid &g, int i0, int j0, int 
 // number of cells of the L-infinity shell s
 __host__ __device__ inline long long shell_count(int s) { return s == 0 ? 1 : 24LL * s * s + 2; }
 
+// first entry of shell s in a shell-ordered array: the (2s-1)^3 cells of all smaller shells come first
+__host__ __device__ inline long long shell_offset(int s) {
+  return s == 0 ? 0 : (long long)(2 * s - 1) * (2 * s - 1) * (2 * s - 1);
+}
+
 // t in [0, shell_count(s)) -> offset (di,dj,dk) with max(|di|,|dj|,|dk|) == s; i runs fastest on
 // the k- and j-faces so that consecutive lanes touch consecutive memory there.
 __device__ __forceinline__ void shell_decode(int s, int t, int &di, int &dj, int &dk) {
@@ -94,6 +101,20 @@ __device__ __forceinline__ void shell_decode(int s, int t, int &di, int &dj, int
   }
 }
 
+// inverse of shell_decode: position of the cell at offset (di,dj,dk) in a shell-ordered array
+__device__ __forceinline__ size_t shell_position(int di, int dj, int dk) {
+  const int ia = di < 0 ? -di : di, ja = dj < 0 ? -dj : dj, ka = dk < 0 ? -dk : dk;
+  const int s = ia > ja ? (ia > ka ? ia : ka) : (ja > ka ? ja : ka);
+  if (s == 0) return 0;
+  const int w = 2 * s + 1, v = 2 * s - 1;
+  const int A = w * w, B = v * w, C = v * v;
+  int t;
+  if (ka == s) t = (dk > 0 ? 0 : A) + (dj + s) * w + (di + s);
+  else if (ja == s) t = 2 * A + (dj > 0 ? 0 : B) + (dk + s - 1) * w + (di + s);
+  else t = 2 * A + 2 * B + (di > 0 ? 0 : C) + (dk + s - 1) * v + (dj + s - 1);
+  return (size_t)shell_offset(s) + (size_t)t;
+}
+
 __device__ __forceinline__ double block_sum(double x, double *sh) {
   // fixed-shape tree: wave shuffle, then the 4 wave sums in order -> deterministic
   for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
@@ -108,15 +129,48 @@ __device__ __forceinline__ double block_sum(double x, double *sh) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// (i,j,k) -> (j,i,k) copies of the four state grids the sweep reads, so that the cells of a
+// shell's i-faces (fixed i, consecutive j) are consecutive in memory too.  32x32 tiles through LDS.
+// src/dst: 4 arrays given by pointer; layout of dst: index = j + n2*(i + n1*k).
+struct Ptr4 {
+  const double *src[4];
+  double *dst[4];
+};
+__global__ void __launch_bounds__(BLOCK)
+k_transpose_ij(Grid g, Ptr4 P) {
+  __shared__ double tile[32][33];
+  const int a = blockIdx.z / g.n3, k = blockIdx.z % g.n3;
+  const double *src = P.src[a] + (size_t)k * g.n1 * g.n2;
+  double *dst = P.dst[a] + (size_t)k * g.n1 * g.n2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + tx, j = j0 + r;
+    if (i < g.n1 && j < g.n2) tile[r][tx] = src[(size_t)i + (size_t)g.n1 * j];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = j0 + tx, i = i0 + r;
+    if (i < g.n1 && j < g.n2) dst[(size_t)j + (size_t)g.n2 * i] = tile[tx][r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column sweep of one shell for every source of the batch (blockIdx.y = source).
 // evolve0D, files_for_3D/evolve_point.F90:114-168 and :237-244, with cinterp
 // (column_density.f90:28-345); boundary photon loss :310-315.
-// col layout: [slot][6][ncell] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII).
+// col layout: [slot][6][colsize] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII), each array in SHELL ORDER
+// (shell_position of the cell's offset from its source): thread t of shell s owns entry
+// shell_offset(s)+t, so all six stores and -- because the corners of consecutive cells are consecutive
+// cells of the previous shell on every face, the i-faces included -- the twelve corner loads are
+// coalesced.  (In mesh order the i-faces of a shell are one cell per 128-byte line.)
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__restrict__ ndens,
-              const double *__restrict__ xh_av, const double *__restrict__ xhe_av, double *__restrict__ col,
+              const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
+              const double *__restrict__ stateT, double *__restrict__ col,
               const BandData *__restrict__ bd, const double *__restrict__ photo_thick,
-              const double *__restrict__ photo_thin, double *__restrict__ loss_partial, int max_blocks) {
+              const double *__restrict__ photo_thin, double *__restrict__ loss_partial, int blocks_total,
+              int block_base) {
   __shared__ double sh[BLOCK / 64];
   const SrcInfo &S = ba.s[blockIdx.y];
   const long long cnt = shell_count(shell);
@@ -128,13 +182,26 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
     const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] &&
                         dk <= S.hi[2];
     if (inside) {
-      const size_t nc = g.ncell;
-      const size_t q = cell_index(g, S.i0, S.j0, S.k0, di, dj, dk);
-      double *cs = col + (size_t)S.slot * 6 * nc;
-      const double nd = ndens[q];
-      const double h0 = dmax(xh_av[q], epsilon);
-      const double he0 = dmax(xhe_av[q], epsilon);
-      const double he1 = dmax(xhe_av[q + nc], epsilon);
+      const size_t nc = g.ncell, cz = g.colsize;
+      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
+      double *cs = col + (size_t)S.slot * 6 * cz;
+      double nd, h0, he0, he1;
+      const int w_ = 2 * shell + 1;
+      if (shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
+        // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies
+        const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
+        const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
+        nd = stateT[qT];
+        h0 = dmax(stateT[qT + nc], epsilon);
+        he0 = dmax(stateT[qT + 2 * nc], epsilon);
+        he1 = dmax(stateT[qT + 3 * nc], epsilon);
+      } else {
+        const size_t q = cell_index(g, S.i0, S.j0, S.k0, di, dj, dk);
+        nd = ndens[q];
+        h0 = dmax(xh_av[q], epsilon);
+        he0 = dmax(xhe_av[q], epsilon);
+        he1 = dmax(xhe_av[q + nc], epsilon);
+      }
       double cin_HI, cin_HeI, cin_HeII, path, vol_ph;
       if (shell == 0) {
         cin_HI = cin_HeI = cin_HeII = 0.0;
@@ -145,8 +212,8 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
         short_characteristic(S.i0, S.j0, S.k0, di, dj, dk, s4);
         size_t qc[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) qc[c] = cell_index(g, S.i0, S.j0, S.k0, s4.ci[c], s4.cj[c], s4.ck[c]);
-        const double *oH = cs + 3 * nc, *oHe0 = cs + 4 * nc, *oHe1 = cs + 5 * nc;
+        for (int c = 0; c < 4; c++) qc[c] = shell_position(s4.ci[c], s4.cj[c], s4.ck[c]);
+        const double *oH = cs + 3 * cz, *oHe0 = cs + 4 * cz, *oHe1 = cs + 5 * cz;
         cin_HI = interp_column(s4, oH[qc[0]], oH[qc[1]], oH[qc[2]], oH[qc[3]], sigma_HI_at_ion_freq);
         cin_HeI = interp_column(s4, oHe0[qc[0]], oHe0[qc[1]], oHe0[qc[2]], oHe0[qc[3]], sigma_HeI_at_ion_freq);
         cin_HeII = interp_column(s4, oHe1[qc[0]], oHe1[qc[1]], oHe1[qc[2]], oHe1[qc[3]], sigma_HeII_at_ion_freq);
@@ -158,12 +225,12 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
       const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
       const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
       const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
-      cs[q] = cin_HI;
-      cs[q + nc] = cin_HeI;
-      cs[q + 2 * nc] = cin_HeII;
-      cs[q + 3 * nc] = cout_HI;
-      cs[q + 4 * nc] = cout_HeI;
-      cs[q + 5 * nc] = cout_HeII;
+      cs[p] = cin_HI;
+      cs[p + cz] = cin_HeI;
+      cs[p + 2 * cz] = cin_HeII;
+      cs[p + 3 * cz] = cout_HI;
+      cs[p + 4 * cz] = cout_HeI;
+      cs[p + 5 * cz] = cout_HeII;
       const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
                             dk == S.hi[2];
       if (boundary && cin_HI < max_coldensh) {
@@ -174,19 +241,34 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
     }
   }
   const double bs = block_sum(loss, sh);
-  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * max_blocks + blockIdx.x] = bs;
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * blocks_total + block_base + blockIdx.x] = bs;
 }
 
-// photon_loss_src_thread(tn) += ... (evolve_point.F90:312): add this shell's block partials, in
-// block order, to the running loss of each source of the batch.
-__global__ void __launch_bounds__(64)
-k_loss_finish(const double *__restrict__ loss_partial, int max_blocks, int nblocks, double *__restrict__ loss_acc) {
-  if (threadIdx.x == 0) {
-    const double *p = loss_partial + (size_t)blockIdx.x * max_blocks;
-    double a = loss_acc[blockIdx.x];
-    for (int i = 0; i < nblocks; i++) a += p[i];
-    loss_acc[blockIdx.x] = a;
-  }
+// photon_loss_src_thread(tn) += ... (evolve_point.F90:312): sum the block partials of all shells of
+// one sub-box round, per source (blockIdx.x).  Fixed shape (256 strided serial sums, then the
+// block tree) => the same bits on every run.
+__global__ void __launch_bounds__(BLOCK)
+k_loss_finish(const double *__restrict__ loss_partial, int blocks_total, int first, int count,
+              double *__restrict__ loss_acc) {
+  __shared__ double sh[BLOCK / 64];
+  const double *p = loss_partial + (size_t)blockIdx.x * blocks_total + first;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < count; i += BLOCK) a += p[i];
+  const double tot = block_sum(a, sh);
+  if (threadIdx.x == 0) loss_acc[blockIdx.x] = tot;
+}
+
+// columns of one slot from shell order back to mesh order (diagnostic download only)
+__global__ void __launch_bounds__(BLOCK)
+k_col_to_grid(Grid g, SrcInfo S, const double *__restrict__ cs, double *__restrict__ out) {
+  const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (q >= g.ncell) return;
+  const int i = (int)(q % g.n1), j = (int)((q / g.n1) % g.n2), k = (int)(q / ((size_t)g.n1 * g.n2));
+  const int di = wrap0(i + 1 - S.i0 + g.l1, g.n1) - g.l1, dj = wrap0(j + 1 - S.j0 + g.l2, g.n2) - g.l2,
+            dk = wrap0(k + 1 - S.k0 + g.l3, g.n3) - g.l3;
+  const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] && dk <= S.hi[2];
+  const size_t p = shell_position(di, dj, dk);
+  for (int c = 0; c < 3; c++) out[q + c * g.ncell] = inside ? cs[p + (size_t)(3 + c) * g.colsize] : 0.0;
 }
 
 // path length of cinterp for an offset, without the corner work (column_density.f90:194,269,341)
@@ -220,17 +302,22 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
   bool touched = false;
   for (int b = 0; b < ba.n; b++) {
     const SrcInfo &S = ba.s[b];
-    const double *cs = col + (size_t)S.slot * 6 * nc;
-    const double cout_HI = cs[q + 3 * nc];
-    if (cout_HI == 0.0) continue; // cell not reached by this source (evolve_point.F90:120, sub-box cut-off)
-    touched = true;
-    const double cin_HI = cs[q], cin_HeI = cs[q + nc], cin_HeII = cs[q + 2 * nc];
-    const double cout_HeI = cs[q + 4 * nc], cout_HeII = cs[q + 5 * nc];
     // unwrapped offset rtpos - srcpos in [-mesh/2, mesh - mesh/2 - 1]
     int di = i + 1 - S.i0, dj = j + 1 - S.j0, dk = k + 1 - S.k0;
     di = wrap0(di + g.l1, g.n1) - g.l1;
     dj = wrap0(dj + g.l2, g.n2) - g.l2;
     dk = wrap0(dk + g.l3, g.n3) - g.l3;
+    // Cells outside the source's last sub-box were never traced (evolve_source.F90:136-144): no
+    // contribution.  (The reference's own marker is coldensh_out == 0, evolve_point.F90:120; every cell
+    // of the box is traced exactly once, so "inside the box" is the same set and needs no zeroing.)
+    if (di < S.lo[0] || di > S.hi[0] || dj < S.lo[1] || dj > S.hi[1] || dk < S.lo[2] || dk > S.hi[2]) continue;
+    touched = true;
+    const size_t cz = g.colsize;
+    const size_t p = shell_position(di, dj, dk);
+    const double *cs = col + (size_t)S.slot * 6 * cz;
+    const double cout_HI = cs[p + 3 * cz];
+    const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
+    const double cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
     double vol_ph;
     if (di == 0 && dj == 0 && dk == 0) {
       vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
@@ -406,14 +493,26 @@ struct c2r_ctx {
   double *d_col = nullptr;
   size_t col_slots = 0;
   double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
-  int max_blocks = 0;
+  int blocks_total = 0;            // blocks of all shells 0..smax
+  std::vector<int> block_base;     // first block of shell s in a partial-sum row
+  double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
+  double *d_stateT = nullptr;      // 4 ncell: (j,i,k)-ordered ndens, xh_av(0), xhe_av(0), xhe_av(1)
   double *h_loss = nullptr; // pinned
   int *d_conv = nullptr;
   int *h_conv = nullptr;    // pinned
-  int last_slot = 0;
+  int last_slot = 0, last_src = 0;
+  int last_lo[3] = {0, 0, 0}, last_hi[3] = {0, 0, 0};
 
   double photon_loss[C2R_NFREQ] = {0};
   int sum_nbox = 0;
+
+  // second stream for the rates kernels: the (latency-bound) column sweep of batch n+1 runs beside
+  // the (ALU-bound) rates kernel of batch n; two scratch sets ping-pong between them
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_sweep_done[2] = {nullptr, nullptr}, ev_rates_done[2] = {nullptr, nullptr};
+  bool set_busy[2] = {false, false};
+  std::vector<hipEvent_t> ev_pool; // timing events, grown on demand
+  size_t ev_used = 0;
 
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -444,7 +543,8 @@ static int alloc_col(c2r_ctx *c) {
   if (c->d_col && c->col_slots >= (size_t)c->batch) return 0;
   if (c->d_col) HIPCHK(c, hipFree(c->d_col));
   c->d_col = nullptr;
-  HIPCHK(c, hipMalloc(&c->d_col, sizeof(double) * 6 * c->g.ncell * c->batch));
+  HIPCHK(c, hipMalloc(&c->d_col, sizeof(double) * 6 * c->g.colsize * c->batch * 2));
+  HIPCHK(c, hipMemset(c->d_col, 0, sizeof(double) * 6 * c->g.colsize * c->batch * 2));
   c->col_slots = c->batch;
   return 0;
 }
@@ -464,6 +564,8 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   c->g.n1 = mesh[0]; c->g.n2 = mesh[1]; c->g.n3 = mesh[2];
   c->g.l1 = mesh[0] / 2; c->g.l2 = mesh[1] / 2; c->g.l3 = mesh[2] / 2;
   c->g.ncell = (size_t)mesh[0] * mesh[1] * mesh[2];
+  c->g.smax = std::max(c->g.l1, std::max(c->g.l2, c->g.l3));
+  c->g.colsize = (size_t)(2 * c->g.smax + 1) * (2 * c->g.smax + 1) * (2 * c->g.smax + 1);
   const size_t nc = c->g.ncell;
 #define CR(call)                                                                                    \
   do {                                                                                              \
@@ -475,7 +577,16 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     }                                                                                               \
   } while (0)
   CR(hipSetDevice(device));
-  CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0; // numerically lower = higher priority
+    CR(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CR(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    CR(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+  }
+  for (int i = 0; i < 2; i++) {
+    CR(hipEventCreateWithFlags(&c->ev_sweep_done[i], hipEventDisableTiming));
+    CR(hipEventCreateWithFlags(&c->ev_rates_done[i], hipEventDisableTiming));
+  }
   CR(hipMalloc(&c->d_ndens, sizeof(double) * nc));
   CR(hipMalloc(&c->d_xh, sizeof(double) * 2 * nc));
   CR(hipMalloc(&c->d_xhe, sizeof(double) * 3 * nc));
@@ -484,14 +595,17 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMalloc(&c->d_xh_int, sizeof(double) * 2 * nc));
   CR(hipMalloc(&c->d_xhe_int, sizeof(double) * 3 * nc));
   CR(hipMalloc(&c->d_temp, sizeof(float) * 3 * nc));
+  CR(hipMalloc(&c->d_stateT, sizeof(double) * 4 * nc));
   c->rates_count = 4 * nc + C2R_NFREQ + 1;
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
   CR(hipMemset(c->d_rates, 0, sizeof(double) * c->rates_count)); // phih_grid = 0 for initial output (evolve_data.F90:77,80)
-  // largest shell: s = max extent
-  int smax = std::max(c->g.l1, std::max(c->g.l2, c->g.l3));
-  c->max_blocks = (int)((shell_count(smax) + BLOCK - 1) / BLOCK);
-  CR(hipMalloc(&c->d_loss_partial, sizeof(double) * (size_t)c->max_blocks * MAXB));
+  // block bookkeeping of the shells 0..smax
+  c->block_base.assign(c->g.smax + 2, 0);
+  for (int s = 0; s <= c->g.smax; s++)
+    c->block_base[s + 1] = c->block_base[s] + (int)((shell_count(s) + BLOCK - 1) / BLOCK);
+  c->blocks_total = c->block_base[c->g.smax + 1];
+  CR(hipMalloc(&c->d_loss_partial, sizeof(double) * (size_t)c->blocks_total * MAXB));
   CR(hipMalloc(&c->d_loss_acc, sizeof(double) * MAXB));
   CR(hipHostMalloc(&c->h_loss, sizeof(double) * MAXB));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
@@ -509,13 +623,19 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv};
+                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->h_conv) (void)hipHostFree(c->h_conv);
   for (auto &ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 2; i++) {
+    if (c->ev_sweep_done[i]) (void)hipEventDestroy(c->ev_sweep_done[i]);
+    if (c->ev_rates_done[i]) (void)hipEventDestroy(c->ev_rates_done[i]);
+  }
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -717,7 +837,21 @@ static int box_smax(const SrcRun &r) {
   return m;
 }
 
-// do_source (evolve_source.F90:66-238) for every source number in `mine`, `batch` at a time
+static int pool_event(c2r_ctx *c, hipEvent_t *out) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreate(&e));
+    c->ev_pool.push_back(e);
+  }
+  *out = c->ev_pool[c->ev_used++];
+  return 0;
+}
+
+// do_source (evolve_source.F90:66-238) for every source number in `mine`, `batch` at a time.
+// Per batch: the column sweep (dependent shell launches, host test of the sub-box loop) on the
+// high-priority stream, then ONE rates launch for the whole batch on the second stream; the next
+// batch's sweep overlaps it (scratch sets ping-pong).  Rates launches are ordered on their stream,
+// so the accumulation over sources keeps the reference's order.
 static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
   HIPCHK(c, hipSetDevice(c->device));
   if (alloc_col(c)) return 1;
@@ -728,9 +862,26 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
   c->tm.sweep_ms = c->tm.rates_ms = 0.0;
   c->tm.sweep_launches = c->tm.rates_launches = 0;
   c->tm.cells_swept = 0;
+  c->ev_used = 0;
+  std::vector<hipEvent_t> tev; // per batch: sweep start, sweep end, rates start, rates end
+  // everything queued earlier on the main stream (state upload, zeroing of the rates) must be
+  // visible to the rates stream
+  HIPCHK(c, hipEventRecord(c->ev_sweep_done[0], c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
 
-  for (size_t b0 = 0; b0 < mine.size(); b0 += c->batch) {
+  {
+    // (j,i,k)-ordered copies of the state the sweep reads (xh_av, xhe_av change every iteration)
+    Ptr4 P;
+    P.src[0] = c->d_ndens; P.src[1] = c->d_xh_av; P.src[2] = c->d_xhe_av; P.src[3] = c->d_xhe_av + nc;
+    for (int a = 0; a < 4; a++) P.dst[a] = c->d_stateT + (size_t)a * nc;
+    hipLaunchKernelGGL(k_transpose_ij, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 4 * g.n3), dim3(BLOCK), 0, c->stream, g, P);
+    HIPCHK(c, hipGetLastError());
+  }
+  int bi = 0;
+  for (size_t b0 = 0; b0 < mine.size(); b0 += c->batch, bi++) {
     const int nb = (int)std::min<size_t>(c->batch, mine.size() - b0);
+    const int set = bi & 1;
+    const int slot0 = set * c->batch;
     std::vector<SrcRun> run(nb);
     for (int b = 0; b < nb; b++) {
       SrcRun &r = run[b];
@@ -743,12 +894,18 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
       r.total_flux = c->normflux[r.ns - 1] * c->s_star;
       r.loss = r.total_flux;
     }
-    // coldensh_out = 0, coldenshe_out = 0 for every new source (evolve_source.F90:94-95): the three
-    // outgoing-column grids of each slot (the incoming ones are fully overwritten where used)
-    for (int b = 0; b < nb; b++)
-      HIPCHK(c, hipMemsetAsync(c->d_col + ((size_t)b * 6 + 3) * nc, 0, sizeof(double) * 3 * nc, c->stream));
+    // coldensh_out = 0 for every new source (evolve_source.F90:94-95) serves two purposes in the
+    // reference: the "already done" marker (replaced here by the shell order: every cell is visited
+    // once) and finite values for corners whose interpolation weight is exactly 0.  The scratch is
+    // zeroed once at allocation and only ever holds finite columns afterwards, so 0*w stays 0.
 
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    // this scratch set may still be read by the rates launch of two batches ago
+    if (c->set_busy[set]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[set], 0));
+    hipEvent_t e_s0 = nullptr, e_s1 = nullptr, e_r0 = nullptr, e_r1 = nullptr;
+    if (c->timing) {
+      if (pool_event(c, &e_s0) || pool_event(c, &e_s1) || pool_event(c, &e_r0) || pool_event(c, &e_r1)) return 1;
+      HIPCHK(c, hipEventRecord(e_s0, c->stream));
+    }
     for (;;) {
       // while-test of evolve_source.F90:136-139 per source
       BatchArgs ba;
@@ -773,7 +930,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
         S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
         for (int d = 0; d < 3; d++) { S.lo[d] = r.last_l[d]; S.hi[d] = r.last_r[d]; }
         S.nflux = c->normflux[r.ns - 1];
-        S.slot = b;
+        S.slot = slot0 + b;
         S.pad = 0;
         act_idx[ba.n] = b;
         ba.n++;
@@ -781,22 +938,19 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
         s_hi = std::max(s_hi, box_smax(r));
       }
       if (ba.n == 0) break;
-      HIPCHK(c, hipMemsetAsync(c->d_loss_acc, 0, sizeof(double) * MAXB, c->stream));
-      // All active sources of a batch are in the same sub-box round (same nbox history is not
-      // required: a source that stopped early simply is not in `ba`), so their new shells are
-      // s_prev+1 .. smax of the new box; sources whose box does not reach a shell skip it by the
-      // in-box test of the kernel.
+      if (s_hi > g.smax) return fail(c, "internal: shell %d beyond smax %d", s_hi, g.smax);
+      // All active sources of a batch are in the same sub-box round (a source that stopped early
+      // simply is not in `ba`), so their new shells are s_prev+1 .. smax of the new box.
       for (int s = s_lo; s <= s_hi; s++) {
-        const long long cnt = shell_count(s);
-        const int nblk = (int)((cnt + BLOCK - 1) / BLOCK);
-        if (nblk > c->max_blocks) return fail(c, "internal: shell %d needs %d blocks > %d", s, nblk, c->max_blocks);
+        const int nblk = c->block_base[s + 1] - c->block_base[s];
         hipLaunchKernelGGL(k_sweep_shell, dim3(nblk, ba.n), dim3(BLOCK), 0, c->stream, g, ba, s, sc, c->d_ndens,
-                           c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin,
-                           c->d_loss_partial, c->max_blocks);
-        hipLaunchKernelGGL(k_loss_finish, dim3(ba.n), dim3(64), 0, c->stream, c->d_loss_partial, c->max_blocks, nblk,
-                           c->d_loss_acc);
-        c->tm.sweep_launches += 2;
+                           c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_col, c->d_bands, c->d_photo_thick,
+                           c->d_photo_thin, c->d_loss_partial, c->blocks_total, c->block_base[s]);
+        c->tm.sweep_launches++;
       }
+      hipLaunchKernelGGL(k_loss_finish, dim3(ba.n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, c->blocks_total,
+                         c->block_base[s_lo], c->block_base[s_hi + 1] - c->block_base[s_lo], c->d_loss_acc);
+      c->tm.sweep_launches++;
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * MAXB, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -815,9 +969,10 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
         r.smax_prev = box_smax(r);
       }
     }
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    if (c->timing) HIPCHK(c, hipEventRecord(e_s1, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_sweep_done[set], c->stream));
 
-    // rates of the whole batch, in source order
+    // rates of the whole batch, in source order, on the second stream
     BatchArgs ba;
     ba.n = nb;
     for (int b = 0; b < nb; b++) {
@@ -826,42 +981,52 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
       S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
       for (int d = 0; d < 3; d++) { S.lo[d] = run[b].last_l[d]; S.hi[d] = run[b].last_r[d]; }
       S.nflux = c->normflux[run[b].ns - 1];
-      S.slot = b;
+      S.slot = slot0 + b;
       S.pad = 0;
     }
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[set], 0));
+    if (c->timing) HIPCHK(c, hipEventRecord(e_r0, c->stream2));
     const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
     if (c->isothermal)
-      hipLaunchKernelGGL(k_rates<false>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, ba, sc, c->d_ndens, c->d_xh_av,
+      hipLaunchKernelGGL(k_rates<false>, dim3(nblk), dim3(BLOCK), 0, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
                          c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
                          c->d_heat_thin, c->d_rates);
     else
-      hipLaunchKernelGGL(k_rates<true>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, ba, sc, c->d_ndens, c->d_xh_av,
+      hipLaunchKernelGGL(k_rates<true>, dim3(nblk), dim3(BLOCK), 0, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
                          c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
                          c->d_heat_thin, c->d_rates);
     HIPCHK(c, hipGetLastError());
     c->tm.rates_launches++;
     if (c->timing) {
-      HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-      HIPCHK(c, hipEventSynchronize(c->ev[2]));
-      float ms = 0;
-      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-      c->tm.sweep_ms += ms;
-      HIPCHK(c, hipEventElapsedTime(&ms, c->ev[1], c->ev[2]));
-      c->tm.rates_ms += ms;
+      HIPCHK(c, hipEventRecord(e_r1, c->stream2));
+      tev.push_back(e_s0); tev.push_back(e_s1); tev.push_back(e_r0); tev.push_back(e_r1);
     }
+    HIPCHK(c, hipEventRecord(c->ev_rates_done[set], c->stream2));
+    c->set_busy[set] = true;
     // photon_loss(1) += photon_loss_src ; sum_nbox += nbox  (evolve_source.F90:233-236), source order
     for (int b = 0; b < nb; b++) {
       c->photon_loss[0] = c->photon_loss[0] + run[b].loss;
       c->sum_nbox += run[b].nbox;
     }
-    c->last_slot = nb - 1;
+    c->last_slot = slot0 + nb - 1;
+    c->last_src = run[nb - 1].ns;
+    for (int d = 0; d < 3; d++) { c->last_lo[d] = run[nb - 1].last_l[d]; c->last_hi[d] = run[nb - 1].last_r[d]; }
   }
   // tail of the reduction buffer: photon_loss(1:47), sum_nbox
   double tail[C2R_NFREQ + 1];
   std::memcpy(tail, c->photon_loss, sizeof c->photon_loss);
   tail[C2R_NFREQ] = (double)c->sum_nbox;
   HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * nc, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->set_busy[0] = c->set_busy[1] = false;
+  for (size_t i = 0; i + 3 < tev.size(); i += 4) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, tev[i], tev[i + 1]));
+    c->tm.sweep_ms += ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, tev[i + 2], tev[i + 3]));
+    c->tm.rates_ms += ms;
+  }
   return 0;
 }
 
@@ -995,13 +1160,21 @@ extern "C" int c2r_upload_iter_state(c2r_ctx *c, const double *xh_av, const doub
 
 extern "C" int c2r_download_columns(c2r_ctx *c, double *coldensh_out, double *coldenshe_out) {
   if (!c) return 1;
-  if (!c->d_col) return fail(c, "c2r_download_columns: no source has been swept yet");
+  if (!c->d_col || c->last_src < 1) return fail(c, "c2r_download_columns: no source has been swept yet");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
-  const double *cs = c->d_col + (size_t)c->last_slot * 6 * nc;
-  if (coldensh_out) HIPCHK(c, hipMemcpyAsync(coldensh_out, cs + 3 * nc, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
+  if (!c->d_colgrid) HIPCHK(c, hipMalloc(&c->d_colgrid, sizeof(double) * 3 * nc));
+  const int *p = &c->srcpos[3 * (size_t)(c->last_src - 1)];
+  const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
+  SrcInfo S{};
+  S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
+  for (int d = 0; d < 3; d++) { S.lo[d] = c->last_lo[d]; S.hi[d] = c->last_hi[d]; }
+  hipLaunchKernelGGL(k_col_to_grid, dim3(nblk), dim3(BLOCK), 0, c->stream, c->g, S,
+                     c->d_col + (size_t)c->last_slot * 6 * c->g.colsize, c->d_colgrid);
+  HIPCHK(c, hipGetLastError());
+  if (coldensh_out) HIPCHK(c, hipMemcpyAsync(coldensh_out, c->d_colgrid, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
   if (coldenshe_out)
-    HIPCHK(c, hipMemcpyAsync(coldenshe_out, cs + 4 * nc, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(coldenshe_out, c->d_colgrid + nc, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

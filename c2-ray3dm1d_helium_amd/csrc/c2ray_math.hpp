@@ -120,6 +120,54 @@ C2R_MHD double log10_(double x) {
   return z + y * log10_2hi;
 }
 
+// log10 for arguments known to be positive and normal (optical depths clamped to >= 1e-20,
+// temperatures): the same operations as log10_/log_core, with the 64-bit integer bookkeeping done
+// on the high 32-bit word (every constant involved has a zero low word, so this is exact) and
+// without the out-of-domain branch.  Bit-identical to log10_ (tests/test_math_host.py).
+C2R_MHD double log10_pos(double x) {
+  const uint64_t ix = asuint64(x);
+  const uint32_t hi = (uint32_t)(ix >> 32), lo = (uint32_t)ix;
+  if (hi - 0x00100000u >= 0x7FE00000u) return log10_(x); // zero, subnormal, negative, inf, nan
+  const double ivln10 = asdouble(0x3FDBCB7B1526E50EULL);
+  const double log10_2hi = asdouble(0x3FD34413509F6000ULL);
+  const double log10_2lo = asdouble(0x3D59FEF311F12B36ULL);
+  const int k = (int)(hi >> 20) - 1023;
+  const int i = (int)((uint32_t)k >> 31);
+  const uint32_t hx = (hi & 0x000FFFFFu) | ((uint32_t)(0x3ff - i) << 20);
+  const double y = (double)(k + i);
+  double lg;
+  const double *H = GMT(log_hdr);
+  if (hx - 0x3FEE0000u < 0x00030900u) {
+    // |x' - 1| small: the polynomial path of log_core
+    lg = log_core(asdouble(((uint64_t)hx << 32) | lo));
+  } else {
+    const double Ln2hi = H[0], Ln2lo = H[1];
+    const double *A = H + 2;
+    const uint32_t th = hx - 0x3FE60000u;
+    const int i2 = (int)((th >> 13) & 127u);
+    const int k2 = (int)th >> 20;
+    const uint32_t izh = hx - (th & 0xFFF00000u);
+    const double z = asdouble(((uint64_t)izh << 32) | lo);
+    const double invc = GMT(log_tab)[2 * i2], logc = GMT(log_tab)[2 * i2 + 1];
+    const double kd = (double)k2;
+    const double r = fma_(z, invc, -1.0);
+    const double w = fma_(kd, Ln2hi, logc);
+    const double t1 = fma_(r, A[2], A[1]);
+    const double hi_ = r + w;
+    const double r2 = r * r;
+    double lo_ = (w - hi_) + r;
+    lo_ = fma_(kd, Ln2lo, lo_);
+    const double r3 = r * r2;
+    const double t2 = fma_(r, A[4], A[3]);
+    const double s_ = fma_(r2, A[0], lo_);
+    const double p_ = fma_(t2, r2, t1);
+    const double q_ = fma_(r3, p_, s_);
+    lg = q_ + hi_;
+  }
+  const double zz = y * log10_2lo + ivln10 * lg;
+  return zz + y * log10_2hi;
+}
+
 // ---- exp: __exp_fma ----------------------------------------------------------------------------
 C2R_MHD double exp_special(double tmp, uint64_t sbits, uint64_t ki) {
   if ((ki & 0x80000000ULL) == 0) { // k > 0: the exponent of scale might have overflowed
@@ -249,4 +297,5 @@ C2R_MHD double pow_(double x, double y) {
 // route the physics through these (c2ray_device.hpp checks for C2R_MATH_EXP)
 #define C2R_MATH_EXP(x) ::c2r::gm::exp_(x)
 #define C2R_MATH_LOG10(x) ::c2r::gm::log10_(x)
+#define C2R_MATH_LOG10P(x) ::c2r::gm::log10_pos(x)
 #define C2R_MATH_POW(x, y) ::c2r::gm::pow_(x, y)

@@ -117,11 +117,17 @@ void hh_cinterp(const int *mesh, const double *cH, const double *cHe, const int 
 // the restated libm (csrc/c2ray_math.hpp) on arrays: op 0 exp, 1 log10, 2 pow
 void hh_math(int op, int n, const double *x, const double *y, double *out) {
   for (int i = 0; i < n; i++)
-    out[i] = op == 0 ? C2R_MATH_EXP(x[i]) : (op == 1 ? C2R_MATH_LOG10(x[i]) : C2R_MATH_POW(x[i], y[i]));
+    out[i] = op == 0 ? C2R_MATH_EXP(x[i])
+                     : (op == 1 ? C2R_MATH_LOG10(x[i]) : (op == 3 ? C2R_MATH_LOG10P(x[i]) : C2R_MATH_POW(x[i], y[i])));
 }
 // the platform libm the reference links (glibc): same ops
 void hh_libm(int op, int n, const double *x, const double *y, double *out) {
-  for (int i = 0; i < n; i++) out[i] = op == 0 ? exp(x[i]) : (op == 1 ? log10(x[i]) : pow(x[i], y[i]));
+  for (int i = 0; i < n; i++) out[i] = op == 0 ? exp(x[i]) : ((op == 1 || op == 3) ? log10(x[i]) : pow(x[i], y[i]));
+}
+
+// div_recip(a, make_recip(b)) on arrays (must equal a/b bit for bit)
+void hh_div_recip(int n, const double *a, const double *b, double *out) {
+  for (int i = 0; i < n; i++) out[i] = div_recip(a[i], make_recip(b[i]));
 }
 
 int hh_constants(double *out, int n) {

@@ -27,6 +27,11 @@ def cases(n, seed=7):
         "log10 tau": (1, 10.0 ** rng.uniform(-20, 4, n), None),
         "log10 near 1": (1, rng.uniform(0.9, 1.1, n), None),
         "log10 exact": (1, np.array([1.0, 10.0, 100.0, 1e-20, 0.5, 2.0, 0.9375, 1.064697265625]), None),
+        "log10_pos wide": (3, 10.0 ** rng.uniform(-300, 300, n), None),
+        "log10_pos tau": (3, 10.0 ** rng.uniform(-20, 4, n), None),
+        "log10_pos near 1": (3, rng.uniform(0.9, 1.1, n), None),
+        "log10_pos exact": (3, np.array([1.0, 10.0, 100.0, 1e-20, 0.5, 2.0, 0.9375, 1.064697265625, 1.0646972656249998,
+                                         0.93749999999999989, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf]), None),
         "pow fits": (2, 10.0 ** rng.uniform(-4, 4, n), rng.uniform(-3, 3, n)),
         "pow x<1": (2, 10.0 ** rng.uniform(-20, 0, n), rng.uniform(0.1, 2.0, n)),
         "pow wide": (2, 10.0 ** rng.uniform(-100, 100, n), rng.uniform(-4, 4, n)),
@@ -43,3 +48,20 @@ def test_bit_identical_to_glibc(harness, name):
         b = run(harness.hh_libm, op, x, y)
     same = (a == b) | (np.isnan(a) & np.isnan(b))
     assert same.all(), (name, x[~same][:4], a[~same][:4], b[~same][:4])
+
+
+def test_division_through_reciprocal_is_correctly_rounded(harness):
+    """div_recip (Markstein's fma correction, csrc/c2ray_device.hpp) == IEEE division, including the
+    guarded corners: huge/tiny operands, zero, all-ones significands, subnormal quotients."""
+    rng = np.random.default_rng(11)
+    n = 10_000_000
+    b = np.ldexp(1.0 + rng.random(n), rng.integers(-100, 100, n))
+    a = np.ldexp(1.0 + rng.random(n), rng.integers(-200, 200, n)) * rng.choice([-1.0, 1.0], n)
+    edge_a = np.array([0.0, 1e-310, 5e-324, 1e300, 1e-200, 3.0, 1.0, 2.0 ** 600, 2.0 ** -600])
+    edge_b = np.array([3.0, 7.0, 1e10, 1e-10, 1e200, np.nextafter(2.0, 0.0), np.nextafter(2.0, 0.0), 3.0, 3.0])
+    a = np.concatenate([a, edge_a])
+    b = np.concatenate([b, edge_b])
+    out = np.empty_like(a)
+    harness.hh_div_recip(a.size, a.ctypes.data_as(dp), b.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    with np.errstate(all="ignore"):
+        assert np.array_equal(out, a / b)
