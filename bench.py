@@ -28,7 +28,20 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
 SWEEP_BYTES_PER_CELL_SOURCE = 136.0   # SURVEY.md section 8(d), isothermal sweep (evolve0D)
+COLUMN_BYTES_PER_CELL_SOURCE = 88.0   # column sweep alone: 40 B state + 48 B columns
+CHEM_BYTES_PER_CELL = 252.0           # SURVEY.md section 8(d), isothermal chemistry pass
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_SUMMARY = ROOT / "profiles" / "r01_bench_pmc_summary.json"
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this same command (tools/pmc_summary.py; FETCH_SIZE doubled as the guide's gfx950
+    correction prescribes), or None."""
+    try:
+        return json.loads(PMC_SUMMARY.read_text())[kernel]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
 
 
 def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0):
@@ -174,12 +187,24 @@ def main():
                        "mesh": n, "sources_per_gpu": a.sources, "batch": a.batch, "coverage": coverage,
                        "parallelism": f"sources over {world} GPU(s), all-reduce of rate grids, replicated chemistry"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_rates",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("k_rates") if (n == 256 and a.sources == 8 and a.batch == 8) else None,
+                         "kernel": "k_rates",
                          "note": "136 B per cell.source (SURVEY 8d) x cells x sources of one launch / mean launch "
-                                 "time (HIP events on the library stream)"},
+                                 "time (HIP events on the library stream); the kernel is FP64-ALU bound (VALU busy "
+                                 "~85 %, profiles/), not HBM bound"},
             "kernel_ms_per_step": {"column_sweep": sweep_ms / a.steps, "rates": rates_ms / a.steps,
                                    "chemistry": chem_ms / a.steps},
+            # the two kernels the north star names, priced the same way (HIP-event time of their launches)
+            "roofline_column_sweep": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                      "achieved": COLUMN_BYTES_PER_CELL_SOURCE * n ** 3 * a.sources * a.steps
+                                      / (sweep_ms * 1e-3) / 1e9,
+                                      "note": "88 B per cell.source; all shell launches of a step incl. boundary-loss work"},
+            "roofline_chemistry": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                   "achieved": CHEM_BYTES_PER_CELL * n ** 3 * a.steps / (chem_ms * 1e-3) / 1e9},
         }
+        for k in ("roofline_column_sweep", "roofline_chemistry"):
+            out[k]["frac"] = out[k]["achieved"] / HBM_PEAK_GBS
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg)
         print(json.dumps(out))

@@ -1,0 +1,57 @@
+"""The N > 1 path with the REAL HIP engine: two ranks (both on cuda:0 of the one-GPU box, gloo as
+transport because RCCL refuses two ranks on one device) share the sources, all-reduce the
+device-resident rate buffer through torch.distributed and replicate the chemistry -- the code path
+bench.py --gpus N runs over RCCL.  The two-rank result is compared with the single-rank one."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT, tap_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import __graft_entry__ as ge
+    from test_host_logic import _inputs
+    pkg = ge.load_package()
+    gold = lambda n: np.load(ROOT / "tests" / "golden" / n)
+    i, o, mesh, mat, grid, src, cosmo = _inputs(pkg, gold, "tap_N16_heat_3src.npz", 2)
+    torch.cuda.set_device(0)
+    ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), device=0, comm=pkg.parallel.TorchComm())
+    n = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
+    if rank == 0:
+        q.put(dict(niter=n, xh=mat.xh, temp=mat.temperature_grid, nbox=ev.sum_nbox_all, loss=ev.photon_loss_all[0],
+                   phih=ev.rates["phih_grid"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu(pkg, gold):
+    _, o = tap_case(gold("tap_N16_heat_3src.npz"), 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = 16 ** 3
+    assert abs(res["niter"] - len(o["conv_flags"])) <= 2
+    assert res["nbox"] == int(o["sum_nbox_all"][0])
+    assert abs(res["loss"] / o["photon_loss_all"][0] - 1) < 1e-9
+    assert abs(res["xh"][n:].mean() / o["xh"][n:].mean() - 1) < 1e-3
+    assert np.max(np.abs(res["xh"] - o["xh"])) < 0.05
+    assert np.all(np.isfinite(res["phih"])) and np.all(res["phih"] >= 0)
