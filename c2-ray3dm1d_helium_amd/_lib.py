@@ -52,6 +52,9 @@ SYMBOLS = {
     "c2r_download_columns": (C.c_int, [C.c_void_p, _dp, _dp]),
     "c2r_upload_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "c2r_upload_iter_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "c2r_state_sums": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "c2r_total_rates": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
+    "c2r_get_reccoef": (C.c_int, [C.c_void_p, _dp]),
     "c2r_rates_count": (C.c_size_t, [C.c_void_p]),
     "c2r_rates_device_ptr": (C.c_void_p, [C.c_void_p]),
     "c2r_set_rates_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

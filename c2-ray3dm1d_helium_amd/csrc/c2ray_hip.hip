@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
-            const double *__restrict__ rates, int *__restrict__ conv_flag) {
+            const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last) {
   const size_t nc = g.ncell;
   const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   int notconv = 0;
@@ -427,6 +427,14 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
         break;
       if (nit > 400) break;
     }
+    // The reference keeps the coefficients in module-global variables (cgsconstants.f90:106-133): after
+    // the global pass they hold what the LAST cell (mesh,mesh,mesh) computed last, and
+    // photonstatistics:total_rates then uses those for every cell.  Export them for the host.
+    if (HEAT && q == nc - 1) {
+      const double v12[12] = {rc.arech0, rc.brech0, rc.areche0, rc.breche0, rc.oreche0, rc.areche1,
+                              rc.breche1, rc.treche1, rc.colli_HI, rc.colli_HeI, rc.colli_HeII, rc.v};
+      for (int n = 0; n < 12; n++) rc_last[n] = v12[n];
+    }
     double temp_av_new = temp_av_old;
     if (HEAT) { // set_temperature_point (mat_ini_test.F90:491-502): stored as REAL(4)
       const float t0 = (float)temper1, t1 = (float)avg_temper;
@@ -451,6 +459,78 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
   // conv_flag = conv_flag + 1 (evolve_point.F90:423): integer count, order-independent
   const unsigned long long m = __ballot(notconv);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(conv_flag, (int)__popcll(m));
+}
+
+// ---------------------------------------------------------------------------------------------
+// photonstatistics.f90: the grid sums of state_before/state_after (:117-144, :208-234) and of
+// total_rates (:150-203).  Fixed launch shape (STAT_BLOCKS x 256, grid-stride, block tree, then one
+// finishing block) => the same bits on every run; the order differs from the reference's serial
+// loops, so the sums agree with it to rounding (~1e-14 relative), not bit for bit.
+constexpr int STAT_BLOCKS = 1024;
+
+template <int NV>
+__device__ __forceinline__ void stat_block_reduce(double (&v)[NV], double *partial) {
+  __shared__ double sh[NV][BLOCK / 64];
+  for (int n = 0; n < NV; n++) {
+    double x = v[n];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[n][threadIdx.x >> 6] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double r = 0.0;
+    for (int i = 0; i < BLOCK / 64; i++) r += sh[threadIdx.x][i];
+    partial[(size_t)blockIdx.x * NV + threadIdx.x] = r;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_state_sums(size_t nc, const double *__restrict__ ndens, const double *__restrict__ xh,
+             const double *__restrict__ xhe, double *__restrict__ partial) {
+  double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nc; q += (size_t)gridDim.x * BLOCK) {
+    const double nd = ndens[q];
+    v[0] += nd * xh[q];
+    v[1] += nd * xh[q + nc];
+    v[2] += nd * xhe[q];
+    v[3] += nd * xhe[q + nc];
+    v[4] += nd * xhe[q + 2 * nc];
+  }
+  stat_block_reduce<5>(v, partial);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+k_total_rates(size_t nc, RecCoef rc, double clumping, const double *__restrict__ ndens,
+              const double *__restrict__ xh, const double *__restrict__ xhe, double *__restrict__ partial) {
+  double v[3] = {0.0, 0.0, 0.0};
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nc; q += (size_t)gridDim.x * BLOCK) {
+    const double nd = ndens[q];
+    const double yh[2] = {xh[q], xh[q + nc]};
+    const double yhe[3] = {xhe[q], xhe[q + nc], xhe[q + 2 * nc]};
+    const double de = electrondens(nd, yh, yhe);
+    v[0] += nd * (yh[1] * rc.brech0 * (1.0 - abu_he) + yhe[1] * rc.breche0 * abu_he * 0.04) * de * clumping;
+    v[1] += nd * de * (yh[0] * rc.colli_HI + yhe[0] * rc.colli_HeI + yhe[1] * rc.colli_HeII);
+    v[2] += nd * abu_he * clumping * (yhe[2] * 1.121 * rc.breche1 + yhe[1] * rc.breche0 * 0.96) * abu_he * de;
+  }
+  stat_block_reduce<3>(v, partial);
+}
+
+template <int NV>
+__global__ void __launch_bounds__(BLOCK)
+k_stat_finish(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+  __shared__ double sh[NV][BLOCK / 64];
+  for (int n = 0; n < NV; n++) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += BLOCK) x += partial[(size_t)i * NV + n];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[n][threadIdx.x >> 6] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double r = 0.0;
+    for (int i = 0; i < BLOCK / 64; i++) r += sh[threadIdx.x][i];
+    out[threadIdx.x] = r;
+  }
 }
 
 } // namespace
@@ -497,6 +577,9 @@ struct c2r_ctx {
   std::vector<int> block_base;     // first block of shell s in a partial-sum row
   double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
   double *d_stateT = nullptr;      // 4 ncell: (j,i,k)-ordered ndens, xh_av(0), xhe_av(0), xhe_av(1)
+  double *d_rc_last = nullptr;     // 12: coefficients left by the last cell of the chemistry pass
+  double *d_stat = nullptr;        // STAT_BLOCKS*5 partials + 8 results
+  double *h_stat = nullptr;        // pinned, 8
   double *h_loss = nullptr; // pinned
   int *d_conv = nullptr;
   int *h_conv = nullptr;    // pinned
@@ -596,6 +679,10 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMalloc(&c->d_xhe_int, sizeof(double) * 3 * nc));
   CR(hipMalloc(&c->d_temp, sizeof(float) * 3 * nc));
   CR(hipMalloc(&c->d_stateT, sizeof(double) * 4 * nc));
+  CR(hipMalloc(&c->d_rc_last, sizeof(double) * 12));
+  CR(hipMemset(c->d_rc_last, 0, sizeof(double) * 12));
+  CR(hipMalloc(&c->d_stat, sizeof(double) * (STAT_BLOCKS * 5 + 8)));
+  CR(hipHostMalloc(&c->h_stat, sizeof(double) * 8));
   c->rates_count = 4 * nc + C2R_NFREQ + 1;
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
@@ -623,11 +710,12 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT};
+                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT, c->d_rc_last, c->d_stat};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->h_conv) (void)hipHostFree(c->h_conv);
+  if (c->h_stat) (void)hipHostFree(c->h_stat);
   for (auto &ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -1057,10 +1145,12 @@ extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   if (c->isothermal)
     hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv);
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_rc_last);
   else
     hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv);
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_rc_last);
   HIPCHK(c, hipGetLastError());
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1175,6 +1265,55 @@ extern "C" int c2r_download_columns(c2r_ctx *c, double *coldensh_out, double *co
   if (coldensh_out) HIPCHK(c, hipMemcpyAsync(coldensh_out, c->d_colgrid, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
   if (coldenshe_out)
     HIPCHK(c, hipMemcpyAsync(coldenshe_out, c->d_colgrid + nc, sizeof(double) * 2 * nc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int c2r_state_sums(c2r_ctx *c, int which, double out5[5]) {
+  if (!c || !out5) return 1;
+  if (!c->have_state || !c->have_step) return fail(c, "c2r_state_sums: state / step not set");
+  if (which < 0 || which > 2) return fail(c, "c2r_state_sums: which = %d not in {0,1,2}", which);
+  HIPCHK(c, hipSetDevice(c->device));
+  const double *xh = which == 0 ? c->d_xh : (which == 1 ? c->d_xh_int : c->d_xh_av);
+  const double *xhe = which == 0 ? c->d_xhe : (which == 1 ? c->d_xhe_int : c->d_xhe_av);
+  hipLaunchKernelGGL(k_state_sums, dim3(STAT_BLOCKS), dim3(BLOCK), 0, c->stream, c->g.ncell, c->d_ndens, xh, xhe, c->d_stat);
+  hipLaunchKernelGGL(k_stat_finish<5>, dim3(1), dim3(BLOCK), 0, c->stream, c->d_stat, STAT_BLOCKS, c->d_stat + STAT_BLOCKS * 5);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_stat, c->d_stat + STAT_BLOCKS * 5, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // h0 = sum*vol*(1-abu_he) ... (photonstatistics.f90:139-143)
+  out5[0] = c->h_stat[0] * c->sc.vol * (1.0 - abu_he);
+  out5[1] = c->h_stat[1] * c->sc.vol * (1.0 - abu_he);
+  out5[2] = c->h_stat[2] * c->sc.vol * abu_he;
+  out5[3] = c->h_stat[3] * c->sc.vol * abu_he;
+  out5[4] = c->h_stat[4] * c->sc.vol * abu_he;
+  return 0;
+}
+
+extern "C" int c2r_total_rates(c2r_ctx *c, double dt, const double reccoef[12], double out3[3]) {
+  if (!c || !reccoef || !out3) return 1;
+  if (!c->have_state || !c->have_step) return fail(c, "c2r_total_rates: state / step not set");
+  HIPCHK(c, hipSetDevice(c->device));
+  RecCoef rc;
+  std::memcpy(&rc, reccoef, sizeof rc);
+  hipLaunchKernelGGL(k_total_rates, dim3(STAT_BLOCKS), dim3(BLOCK), 0, c->stream, c->g.ncell, rc, c->sc.clumping,
+                     c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stat);
+  hipLaunchKernelGGL(k_stat_finish<3>, dim3(1), dim3(BLOCK), 0, c->stream, c->d_stat, STAT_BLOCKS, c->d_stat + STAT_BLOCKS * 5);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_stat, c->d_stat + STAT_BLOCKS * 5, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int n = 0; n < 3; n++) out3[n] = c->h_stat[n] * c->sc.vol * dt; // photonstatistics.f90:199-201
+  return 0;
+}
+
+extern "C" int c2r_get_reccoef(c2r_ctx *c, double out12[12]) {
+  if (!c || !out12) return 1;
+  if (c->isothermal) {
+    std::memcpy(out12, &c->sc.rc, sizeof(double) * 12);
+    return 0;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(out12, c->d_rc_last, sizeof(double) * 12, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -257,6 +257,23 @@ class HipEngine:
         self._chk(self.lib.c2r_download_columns(self.h, _dp(a), _dp(b)))
         return dict(coldensh_out=a, coldenshe_out=b)
 
+    # -- photon statistics (photonstatistics.f90) on the device -----------------------------------
+    def state_sums(self, which=0):
+        out = np.empty(5)
+        self._chk(self.lib.c2r_state_sums(self.h, int(which), _dp(out)))
+        return out
+
+    def total_rates(self, dt, reccoef):
+        out = np.empty(3)
+        rc = _f64(reccoef).reshape(-1)
+        self._chk(self.lib.c2r_total_rates(self.h, float(dt), _dp(rc), _dp(out)))
+        return out
+
+    def get_reccoef(self):
+        out = np.empty(12)
+        self._chk(self.lib.c2r_get_reccoef(self.h, _dp(out)))
+        return out
+
     # -- reduction buffer ----------------------------------------------------------------------
     def rates_count(self):
         return int(self.lib.c2r_rates_count(self.h))

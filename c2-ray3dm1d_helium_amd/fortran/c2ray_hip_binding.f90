@@ -172,6 +172,27 @@ module c2ray_hip
        real(c_double), intent(out) :: coldensh_out(*), coldenshe_out(*)
      end function c2r_download_columns
 
+     integer(c_int) function c2r_state_sums(ctx, which, out5) bind(C, name="c2r_state_sums")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which
+       real(c_double), intent(out) :: out5(5)
+     end function c2r_state_sums
+
+     integer(c_int) function c2r_total_rates(ctx, dt, reccoef, out3) bind(C, name="c2r_total_rates")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       real(c_double), intent(in) :: reccoef(12)
+       real(c_double), intent(out) :: out3(3)
+     end function c2r_total_rates
+
+     integer(c_int) function c2r_get_reccoef(ctx, out12) bind(C, name="c2r_get_reccoef")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: out12(12)
+     end function c2r_get_reccoef
+
      integer(c_size_t) function c2r_rates_count(ctx) bind(C, name="c2r_rates_count")
        import :: c_size_t, c_ptr
        type(c_ptr), value :: ctx

@@ -25,7 +25,8 @@ module evolve
   use cosmology_parameters, only: H0, Omega0
   use cgsconstants, only: arech0, brech0, areche0, breche0, oreche0, areche1, breche1, treche1
   use cgsconstants, only: colli_HI, colli_HeI, colli_HeII, v
-  use photonstatistics, only: state_before, calculate_photon_statistics, photon_loss, LLS_loss
+  use photonstatistics, only: photon_loss, LLS_loss
+  use photonstatistics, only: totrec, totcollisions, recomions, dh0, dhe0, dhe2, total_ion
   use photonstatistics, only: report_photonstatistics, update_grandtotal_photonstatistics
   use evolve_data, only: phih_grid, phihe_grid, phiheat
   use evolve_data, only: xh_av, xhe_av, xh_intermed, xhe_intermed
@@ -64,6 +65,7 @@ contains
     integer :: n
     integer(c_int) :: iso
     real(kind=dp) :: reccoef(12)
+    real(kind=dp) :: before(5), after(5), rates3(3)
     type(c_ptr) :: tptr
 
     if (restart /= 0) then
@@ -75,9 +77,6 @@ contains
             "all-reduce / c2r_global_pass themselves (see INTEGRATION.md); npr = ", npr
        stop 1
     endif
-
-    ! Initial state (for photon statistics)
-    call state_before (xh,xhe)
 
     if (.not. tables_uploaded) call upload_tables ()
 
@@ -99,6 +98,9 @@ contains
     if (.not.isothermal) tptr = c_loc_real4 (temperature_grid)
     call check (c2r_upload_state (hip_ctx, xh, xhe, tptr), "c2r_upload_state")
 
+    ! Initial state (for photon statistics): state_before (photonstatistics.f90:117-144), on the device
+    call check (c2r_state_sums (hip_ctx, 0_c_int, before), "c2r_state_sums")
+
     if (rank == 0) write(timefile,"(A,F8.1)") &
          "Time before starting iteration: ", timestamp_wallclock ()
 
@@ -109,8 +111,8 @@ contains
     call check (c2r_download_state (hip_ctx, xh, xhe, tptr), "c2r_download_state")
     call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
          "c2r_download_rates")
-    call check (c2r_download_iter_state (hip_ctx, xh_av, xhe_av, xh_intermed, xhe_intermed), &
-         "c2r_download_iter_state")
+    ! xh_av, xhe_av, xh_intermed, xhe_intermed stay on the device: nothing outside the evolve chain
+    ! reads them (c2r_download_iter_state fetches them when a dump is wanted)
     sum_nbox = nbox
     sum_nbox_all = nbox
     ! global_pass leaves the mean loss per cell in photonstatistics:photon_loss (evolve.F90:457)
@@ -132,8 +134,27 @@ contains
             "Time after iteration ",niter," : ", timestamp_wallclock ()
     endif
 
-    ! Calculate photon statistics
-    call calculate_photon_statistics (dt,xh,xh_av,xhe,xhe_av)
+    ! The reference's global pass leaves the temperature-dependent coefficients of the last cell in the
+    ! module variables of cgsconstants (evolve_point.F90:543); photon statistics use them
+    if (.not.isothermal) then
+       call check (c2r_get_reccoef (hip_ctx, reccoef), "c2r_get_reccoef")
+       arech0=reccoef(1); brech0=reccoef(2); areche0=reccoef(3); breche0=reccoef(4)
+       oreche0=reccoef(5); areche1=reccoef(6); breche1=reccoef(7); treche1=reccoef(8)
+       colli_HI=reccoef(9); colli_HeI=reccoef(10); colli_HeII=reccoef(11); v=reccoef(12)
+    endif
+
+    ! Calculate photon statistics: calculate_photon_statistics (dt,xh,xh_av,xhe,xhe_av) of
+    ! evolve.F90:225 = state_after(xh,xhe) + total_rates(dt,xh_av,xhe_av) + total_ionizations, with
+    ! the grid reductions done on the device
+    call check (c2r_state_sums (hip_ctx, 0_c_int, after), "c2r_state_sums")
+    call check (c2r_total_rates (hip_ctx, dt, reccoef, rates3), "c2r_total_rates")
+    totrec=rates3(1)
+    totcollisions=rates3(2)
+    recomions=rates3(3)
+    dh0=before(1)-after(1)
+    dhe0=before(3)-after(3)
+    dhe2=after(5)-before(5)
+    total_ion=dh0+dhe0+dhe2
     call report_photonstatistics (dt)
     call update_grandtotal_photonstatistics (dt)
 

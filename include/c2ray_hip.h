@@ -108,6 +108,22 @@ int c2r_upload_iter_state(c2r_ctx *ctx, const double *xh_av, const double *xhe_a
 /* evolve_data: coldensh_out, coldenshe_out(:,:,:,0:1) of the source swept last (diagnostic). */
 int c2r_download_columns(c2r_ctx *ctx, double *coldensh_out, double *coldenshe_out);
 
+/* Photon statistics on the device (files_for_3D/photonstatistics.f90) -- the grid reductions the
+ * reference runs on the host before and after every evolve3D call:
+ *   c2r_state_sums   state_before (:117-144) / state_after (:208-234): number of H0, H+, He0, He+, He++
+ *                    (sum of ndens*x times vol*(1-abu_he) or vol*abu_he) of which = 0: xh,xhe;
+ *                    1: xh_intermed,xhe_intermed; 2: xh_av,xhe_av
+ *   c2r_total_rates  total_rates (:150-203) on the time-averaged fractions xh_av,xhe_av with the given
+ *                    twelve coefficients: out = totrec, totcollisions, recomions (already x vol x dt)
+ *   c2r_get_reccoef  the module-global coefficients of cgsconstants.f90:106-133 as the reference's
+ *                    global pass leaves them (isothermal: unchanged; otherwise what the last cell
+ *                    (mesh,mesh,mesh) computed last, evolve_point.F90:543) -- total_rates uses these.
+ * The sums are deterministic but associate differently from the reference's serial loops: they agree
+ * with it to rounding, not bit for bit. */
+int c2r_state_sums(c2r_ctx *ctx, int which, double out5[5]);
+int c2r_total_rates(c2r_ctx *ctx, double dt, const double reccoef[12], double out3[3]);
+int c2r_get_reccoef(c2r_ctx *ctx, double out12[12]);
+
 /* The buffer that mpi_accumulate_grid_quantities (evolve.F90:505-548) sums over ranks, as ONE
  * contiguous device array of c2r_rates_count() doubles:
  *   [ phih_grid | phihe_grid(0) | phihe_grid(1) | phiheat | photon_loss(1:47) | sum_nbox ]

@@ -245,3 +245,45 @@ def test_full_size_properties_256(pkg, tables):
     assert np.all(out[0]["phih_grid"] > 0)
     assert out[0]["sum_nbox"] == 8 * 13  # 13 sub-boxes of 10 cells reach 128/127 cells at N = 256
     e.close()
+
+
+@pytest.mark.parametrize("fname,call", [("tap_N16_heat_3src.npz", 1), ("tap_N16_iso_1src.npz", 2)])
+def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
+    """The grid reductions of photonstatistics.f90 (state_before/after, total_rates) computed on the
+    device equal the reference's serial sums to rounding, and the module-global recombination
+    coefficients the reference's global pass leaves behind (cgsconstants) are reproduced bit for bit."""
+    i, o = tap_case(gold(fname), call)
+    mesh, mat, grid, src, cosmo = make_inputs(pkg, i)
+    ev = pkg.Evolve(mesh, tables, device=0)
+    e = ev.engine
+    e.set_step(mat, grid, cosmo)
+    e.set_sources(src)
+    e.upload_state(mat)
+    n = int(np.prod(mesh))
+    abu_he = float(np.float32(0.074))
+    nd, vol = i["ndens"], float(i["vol"][0])
+
+    def serial(xh, xhe):
+        f = [1 - abu_he, 1 - abu_he, abu_he, abu_he, abu_he]
+        comp = [xh[:n], xh[n:], xhe[:n], xhe[n:2 * n], xhe[2 * n:]]
+        return np.array([np.sum(nd * c) * vol * w for c, w in zip(comp, f)])
+
+    before = e.state_sums(0)
+    assert np.allclose(before, serial(i["xh"], i["xhe"]), rtol=1e-12, atol=0)
+    niter, _ = e.evolve3d(float(i["dt"][0]))
+    assert niter == len(o["conv_flags"])
+    after = e.state_sums(0)
+    assert np.allclose(after, serial(o["xh"], o["xhe"]), rtol=1e-12, atol=0)
+    rc = e.get_reccoef()
+    assert np.array_equal(rc, o["reccoef"])          # what the reference's module variables hold afterwards
+    # total_rates (photonstatistics.f90:150-203) with those coefficients on xh_av, xhe_av
+    xh_av, xhe_av = o["xh_av"], o["xhe_av"]
+    de = nd * (xh_av[n:] * (1 - abu_he) + float(np.float32(7.1e-7)) + abu_he * (xhe_av[n:2 * n] + 2.0 * xhe_av[2 * n:]))
+    clump = float(i["clumping"][0])
+    dt = float(i["dt"][0])
+    totrec = np.sum(nd * (xh_av[n:] * rc[1] * (1 - abu_he) + xhe_av[n:2 * n] * rc[3] * abu_he * 0.04) * de * clump) * vol * dt
+    totcol = np.sum(nd * de * (xh_av[:n] * rc[8] + xhe_av[:n] * rc[9] + xhe_av[n:2 * n] * rc[10])) * vol * dt
+    recom = np.sum(nd * abu_he * clump * (xhe_av[2 * n:] * 1.121 * rc[6] + xhe_av[n:2 * n] * rc[3] * 0.96) * abu_he * de) * vol * dt
+    got = e.total_rates(dt, rc)
+    assert np.allclose(got, [totrec, totcol, recom], rtol=1e-12, atol=0)
+    e.close()
