@@ -19,6 +19,7 @@ Outputs (all data, no reference source text):
 """
 from __future__ import annotations
 
+import shutil
 import subprocess
 import sys
 from pathlib import Path
@@ -94,6 +95,8 @@ def main():
             np.savez_compressed(GOLD / "funcvec.npz", **fv)
             tb = refrun.read_records(res / "tables.bin")
             np.savez_compressed(GOLD / "coolin_probe.npz", coolin_probe=tb["coolin_probe"])
+    for d in refrun.REFDIR.glob("golden_*"):
+        shutil.rmtree(d)  # run directories are scratch
     for p in sorted(list(GOLD.glob("*.npz")) + list(PKGDATA.glob("*.npz"))):
         print(f"{p.name:32s} {p.stat().st_size/1024:8.1f} KiB")
 

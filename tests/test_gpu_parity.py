@@ -287,3 +287,43 @@ def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
     got = e.total_rates(dt, rc)
     assert np.allclose(got, [totrec, totcol, recom], rtol=1e-12, atol=0)
     e.close()
+
+
+def test_config2_64cube_point_source_vs_reference(pkg, tables, gold):
+    """BASELINE configs[1]: 64^3 uniform density, one point source (1e54 photons/s, 5e4 K black body),
+    heating on, four consecutive evolve3D calls (83 outer iterations) chained exactly as the
+    reference's driver chains them.  Every output array has the SHA-256 of the reference's, the
+    iteration history is the same, and so is the ionisation front along the line through the source."""
+    import hashlib
+    z = gold("n64_heat_1src.npz")
+    n = 64
+    nc = n ** 3
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    xh = np.repeat(z["c1_xh_uniform"], nc)
+    xhe = np.repeat(z["c1_xhe_uniform"], nc)
+    temp = np.repeat(z["c1_temperature_uniform"].astype(np.float32), nc)
+    ev = pkg.Evolve((n, n, n), tables, device=0)
+    log = {}
+    for call in range(1, int(z["ncalls"]) + 1):
+        g = lambda k: z[f"c{call}_{k}"]
+        mat = pkg.Material(np.full(nc, float(g("ndens_uniform"))), xh, xhe, temp, False, float(g("temper_val")[0]),
+                           float(g("clumping")[0]), g("reccoef"))
+        grid = pkg.GridProps((n, n, n), tuple(g("dr")), float(g("vol")[0]))
+        src = pkg.SourceProps(g("srcpos").reshape(-1, 3), g("NormFlux"), float(g("S_star")[0]))
+        cosmo = pkg.Cosmology(float(g("zred")[0]), float(g("H0")[0]), float(g("Omega0")[0]))
+        niter = ev.evolve3D(0.0, float(g("dt")[0]), 0, mat, grid, src, cosmo)
+        assert ev.conv_flags == [int(x) for x in g("conv_flags")], call
+        assert niter == len(g("conv_flags"))
+        xh, xhe, temp = mat.xh, mat.xhe, mat.temperature_grid
+        got = {"xh": xh, "xhe": xhe, "temperature": temp, **ev.rates, **ev.iter_state}
+        for k in ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av"]:
+            assert sha(got[k]) == str(g("sha_" + k)), (call, k)
+        line = xh[nc:].reshape(n, n, n, order="F")[:, 31, 31]
+        assert np.array_equal(line, g("xHII_line"))
+        # I-front radius (x_HII = 0.5 crossing on the +x side of the source), in cells
+        i0 = 31
+        r = next((i - i0 for i in range(i0, n) if line[i] < 0.5), None)
+        log[f"call{call}"] = dict(niter=niter, ifront_cells=r, xHII_at_source=float(line[i0]))
+        assert np.array_equal(ev.engine.get_reccoef(), g("reccoef_after"))
+        assert ev.sum_nbox_all == int(g("sum_nbox")[0])
+    dump(log, "config2_n64.json")
