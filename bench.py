@@ -89,6 +89,41 @@ def cpu_baseline(pkg, mesh=96, nsrc=2):
             "sample": f"{mesh}^3 box, {nsrc} sources, 1 outer iteration (sweep + chemistry), {dt:.1f} s of CPU"}
 
 
+def cpu_baseline_reference(mesh=64):
+    """The reference ITSELF (flang -O2 build of /root/reference made by oracle/ref_build.sh in the dev
+    container; the binary travels in oracle/_ref/) on its own test problem: mesh^3, one 1e54 source,
+    isothermal, four time slices.  Wall time of the evolve3D iterations from the reference's own
+    Timings.log stamps (evolve.F90:150,220).  Returns None when the binary is not there."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import re
+    import shutil
+    import refrun
+    omp = refrun.ref_binary(mesh, "test", omp=True).exists()
+    if not omp and not refrun.ref_binary(mesh, "test").exists():
+        return None
+    # the reference's OpenMP path is at most 8-way (6 axes / 12 planes / 8 octants, evolve_source.F90:158-189)
+    threads = min(8, os.cpu_count() or 1) if omp else 1
+    run = refrun.run_reference(mesh, [(mesh // 2, mesh // 2, mesh // 2, 1e54)], isothermal=True, steps_per_slice=1,
+                               which="test", omp=omp, threads=threads, name="bench_reference_run")
+    text = (run / "results" / "Timings.log").read_text(errors="replace")
+    total, niter, t0 = 0.0, 0, None
+    for line in text.splitlines():
+        m = re.search(r"Time before starting iteration:\s*([\d.]+)", line)
+        if m:
+            t0 = float(m.group(1))
+        m = re.search(r"Time after iteration\s+(\d+)\s*:\s*([\d.]+)", line)
+        if m and t0 is not None:
+            total += float(m.group(2)) - t0
+            t0 = float(m.group(2))
+            niter += 1
+    shutil.rmtree(run, ignore_errors=True)
+    if niter == 0 or total <= 0:
+        return None
+    return {"value": mesh ** 3 * niter / total, "unit": "cell-updates/s", "cores": threads, "kind": "reference",
+            "sample": f"reference binary (flang -O2{', OpenMP' if omp else ', serial'}), {mesh}^3 box, 1 source, isothermal, {niter} outer "
+                      f"iterations of evolve3D in {total:.1f} s (nominal mesh^3 x sources per iteration, as the metric)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +241,10 @@ def main():
         for k in ("roofline_column_sweep", "roofline_chemistry"):
             out[k]["frac"] = out[k]["achieved"] / HBM_PEAK_GBS
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pkg)
+            port = cpu_baseline(pkg)
+            ref = cpu_baseline_reference()
+            out["cpu_baseline"] = ref if ref is not None else port
+            out["cpu_baseline_port"] = port
         print(json.dumps(out))
     if comm is not None:
         comm.dist.destroy_process_group()
