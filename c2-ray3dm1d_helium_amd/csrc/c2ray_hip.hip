@@ -285,7 +285,7 @@ __device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
 // (evolve_point.F90:246-306 with photoion_rates, radiation_photoionrates.f90:108-277).
 // rates layout: [phih | phihe0 | phihe1 | phiheat] each ncell.
 template <bool HEAT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, HEAT ? 3 : 5)
 k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
         const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
         const double *__restrict__ photo_thick, const double *__restrict__ photo_thin,

@@ -107,12 +107,20 @@ C2R_MHD double log_core(double x) {
 
 // ---- log10: __ieee754_log10 (sysdeps/ieee754/dbl-64/e_log10.c, generic build, no fma) ----------
 C2R_MHD double log10_(double x) {
-  const uint64_t ix = asuint64(x);
-  if (ix - 0x0010000000000000ULL >= 0x7FF0000000000000ULL - 0x0010000000000000ULL) return ::log10(x);
+  uint64_t ix = asuint64(x);
   const double ivln10 = asdouble(0x3FDBCB7B1526E50EULL);
   const double log10_2hi = asdouble(0x3FD34413509F6000ULL);
   const double log10_2lo = asdouble(0x3D59FEF311F12B36ULL);
-  int k = (int)(ix >> 52) - 1023;
+  int k = 0;
+  if (ix - 0x0010000000000000ULL >= 0x7FF0000000000000ULL - 0x0010000000000000ULL) {
+    // e_log10.c: x < 2^-1022, or inf / nan
+    if ((ix << 1) == 0) return -0x1p54 / fabs(x);              // log(+-0) = -inf
+    if ((int64_t)ix < 0) return (x - x) / (x - x);             // log(-#) = NaN
+    if (ix >= 0x7FF0000000000000ULL) return x + x;             // inf, nan
+    k = -54;                                                   // subnormal: scale up
+    ix = asuint64(x * 0x1p54);
+  }
+  k += (int)(ix >> 52) - 1023;
   const int i = k < 0 ? 1 : 0;
   const uint64_t hx = (ix & 0x000FFFFFFFFFFFFFULL) | ((uint64_t)(0x3ff - i) << 52);
   const double y = (double)(k + i);
@@ -233,10 +241,19 @@ C2R_MHD double exp_(double x) {
 }
 
 // ---- pow: __pow_fma ----------------------------------------------------------------------------
+// x <= 0, subnormal, inf, nan, or |y| < 2^-65 / >= 2^63: never reached on the hot path (bases are
+// temperatures, ratios of temperatures and ionised fractions >= 1e-20; exponents are fit constants).
+// Kept out of line so that the platform pow's code and registers stay out of the kernels.
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline)) inline double pow_out_of_domain(double x, double y) { return ::pow(x, y); }
+#else
+inline double pow_out_of_domain(double x, double y) { return ::pow(x, y); }
+#endif
+
 C2R_MHD double pow_(double x, double y) {
   const uint64_t ix = asuint64(x), iy = asuint64(y);
   const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
-  if (topx - 1u > 0x7fdu || (topy & 0x7ffu) - 0x3beu > 0x7fu) return ::pow(x, y);
+  if (topx - 1u > 0x7fdu || (topy & 0x7ffu) - 0x3beu > 0x7fu) return pow_out_of_domain(x, y);
   // log_inline
   const double *H = GMT(pow_hdr);
   const double Ln2hi = H[0], Ln2lo = H[1];

@@ -327,3 +327,42 @@ def test_config2_64cube_point_source_vs_reference(pkg, tables, gold):
         assert np.array_equal(ev.engine.get_reccoef(), g("reccoef_after"))
         assert ev.sum_nbox_all == int(g("sum_nbox")[0])
     dump(log, "config2_n64.json")
+
+
+@pytest.mark.parametrize("mesh,iso", [((12, 16, 20), True), ((20, 12, 14), False)])
+def test_non_cubic_mesh_vs_oracle(pkg, orc, otables, tables, mesh, iso):
+    """mesh(1) /= mesh(2) /= mesh(3): per-dimension box limits, the while-test of do_source that looks
+    at the z extent only (evolve_source.F90:136-139), shells clipped differently per axis."""
+    rng = np.random.default_rng(7 + mesh[0])
+    hp = pkg.hostphys
+    zred = 9.0
+    dr1 = hp.test_grid(16, zred)[0][0]
+    dr = (dr1, 1.1 * dr1, 0.9 * dr1)
+    vol = dr[0] * dr[1] * dr[2]
+    nc = int(np.prod(mesh))
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc))
+    x = 10.0 ** rng.uniform(-5, -0.5, nc)
+    xh = np.concatenate([1.0 - x, x])
+    xhe = np.concatenate([1.0 - x, 0.7 * x, 0.3 * x])
+    temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.2, nc))).astype(np.float32), 3)
+    srcpos = np.array([[1, mesh[1], mesh[2] // 2], [mesh[0] // 2, 3, mesh[2]]], dtype=np.int32)
+    flux = np.array([3.0e7, 8.0e6])
+    mat = pkg.Material(ndens, xh, xhe, temp, iso, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps(mesh, dr, vol)
+    src = pkg.SourceProps(srcpos, flux, 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    dt = 3.0e6 * hp.YEAR
+    ev = pkg.Evolve(mesh, tables, device=0)
+    niter = ev.evolve3D(0.0, dt, 0, mat, grid, src, cosmo)
+    st = orc.Step(mesh, dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens, hp.reccoef(1.0e4))
+    s = orc.State(st, xh, xhe, temp)
+    nref = orc.evolve3d(otables, st, s, dt)
+    assert niter == nref and ev.conv_flags == s.conv_flags
+    assert np.array_equal(mat.xh, s.xh) and np.array_equal(mat.xhe, s.xhe)
+    if not iso:
+        assert np.array_equal(mat.temperature_grid, s.temperature)
+    r = ev.rates
+    assert np.array_equal(r["phih_grid"], s.phih) and np.array_equal(r["phihe_grid"], s.phihe)
+    assert r["sum_nbox"] == s.c.sum_nbox
+    cols = ev.engine.download_columns()
+    assert np.array_equal(cols["coldensh_out"], s.coldensh_out)
