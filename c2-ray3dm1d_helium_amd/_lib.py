@@ -48,11 +48,13 @@ SYMBOLS = {
     "c2r_global_pass": (C.c_int, [C.c_void_p, C.c_double, _ip]),
     "c2r_end_step": (C.c_int, [C.c_void_p]),
     "c2r_download_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
+    "c2r_get_loss": (C.c_int, [C.c_void_p, _dp, _ip]),
     "c2r_download_iter_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "c2r_download_columns": (C.c_int, [C.c_void_p, _dp, _dp]),
     "c2r_upload_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "c2r_upload_iter_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "c2r_state_sums": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "c2r_fraction_means": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "c2r_total_rates": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
     "c2r_get_reccoef": (C.c_int, [C.c_void_p, _dp]),
     "c2r_rates_count": (C.c_size_t, [C.c_void_p]),

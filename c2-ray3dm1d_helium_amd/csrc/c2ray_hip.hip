@@ -489,7 +489,7 @@ k_state_sums(size_t nc, const double *__restrict__ ndens, const double *__restri
              const double *__restrict__ xhe, double *__restrict__ partial) {
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nc; q += (size_t)gridDim.x * BLOCK) {
-    const double nd = ndens[q];
+    const double nd = ndens ? ndens[q] : 1.0; // ndens == nullptr: plain sums of the fractions
     v[0] += nd * xh[q];
     v[1] += nd * xh[q + nc];
     v[2] += nd * xhe[q];
@@ -1207,6 +1207,13 @@ extern "C" int c2r_download_rates(c2r_ctx *c, double *phih, double *phihe, doubl
   return 0;
 }
 
+extern "C" int c2r_get_loss(c2r_ctx *c, double *photon_loss47, int *sum_nbox) {
+  if (!c) return 1;
+  if (photon_loss47) std::memcpy(photon_loss47, c->photon_loss, sizeof c->photon_loss);
+  if (sum_nbox) *sum_nbox = c->sum_nbox;
+  return 0;
+}
+
 extern "C" int c2r_download_iter_state(c2r_ctx *c, double *xh_av, double *xhe_av, double *xh_intermed,
                                        double *xhe_intermed) {
   if (!c) return 1;
@@ -1287,6 +1294,23 @@ extern "C" int c2r_state_sums(c2r_ctx *c, int which, double out5[5]) {
   out5[2] = c->h_stat[2] * c->sc.vol * abu_he;
   out5[3] = c->h_stat[3] * c->sc.vol * abu_he;
   out5[4] = c->h_stat[4] * c->sc.vol * abu_he;
+  return 0;
+}
+
+extern "C" int c2r_fraction_means(c2r_ctx *c, int which, double out5[5]) {
+  if (!c || !out5) return 1;
+  if (!c->have_state) return fail(c, "c2r_fraction_means: state not set");
+  if (which < 0 || which > 2) return fail(c, "c2r_fraction_means: which = %d not in {0,1,2}", which);
+  HIPCHK(c, hipSetDevice(c->device));
+  const double *xh = which == 0 ? c->d_xh : (which == 1 ? c->d_xh_int : c->d_xh_av);
+  const double *xhe = which == 0 ? c->d_xhe : (which == 1 ? c->d_xhe_int : c->d_xhe_av);
+  hipLaunchKernelGGL(k_state_sums, dim3(STAT_BLOCKS), dim3(BLOCK), 0, c->stream, c->g.ncell, (const double *)nullptr, xh, xhe,
+                     c->d_stat);
+  hipLaunchKernelGGL(k_stat_finish<5>, dim3(1), dim3(BLOCK), 0, c->stream, c->d_stat, STAT_BLOCKS, c->d_stat + STAT_BLOCKS * 5);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_stat, c->d_stat + STAT_BLOCKS * 5, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int n = 0; n < 5; n++) out5[n] = c->h_stat[n] / (double)c->g.ncell;
   return 0;
 }
 

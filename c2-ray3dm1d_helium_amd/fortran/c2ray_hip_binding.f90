@@ -145,6 +145,13 @@ module c2ray_hip
        integer(c_int), intent(out) :: sum_nbox
      end function c2r_download_rates
 
+     integer(c_int) function c2r_get_loss(ctx, photon_loss, sum_nbox) bind(C, name="c2r_get_loss")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: photon_loss(*)
+       integer(c_int), intent(out) :: sum_nbox
+     end function c2r_get_loss
+
      integer(c_int) function c2r_download_iter_state(ctx, xh_av, xhe_av, xh_intermed, xhe_intermed) &
           bind(C, name="c2r_download_iter_state")
        import :: c_int, c_ptr, c_double
@@ -178,6 +185,13 @@ module c2ray_hip
        integer(c_int), value :: which
        real(c_double), intent(out) :: out5(5)
      end function c2r_state_sums
+
+     integer(c_int) function c2r_fraction_means(ctx, which, out5) bind(C, name="c2r_fraction_means")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which
+       real(c_double), intent(out) :: out5(5)
+     end function c2r_fraction_means
 
      integer(c_int) function c2r_total_rates(ctx, dt, reccoef, out3) bind(C, name="c2r_total_rates")
        import :: c_int, c_ptr, c_double

@@ -1,16 +1,21 @@
 !> Drop-in replacement of the reference's module evolve (files_for_3D/evolve.F90): same module
-!! name, same public symbol `evolve3D(time,dt,restart)` with the same meaning; the convergence loop
-!! {zero rates -> all sources -> global chemistry pass} runs on the GPU through the C ABI of
+!! name, same public symbol `evolve3D(time,dt,restart)` with the same meaning.  The convergence loop
+!! {zero rates -> all sources -> (sum over ranks) -> global chemistry pass} is driven from here, as in
+!! the reference, but every grid operation runs on the GPU through the C ABI of
 !! include/c2ray_hip.h (module c2ray_hip).  Everything around it -- the driver, source lists,
-!! material set-up, cosmology, output routines, photon statistics -- is the reference's own code,
-!! untouched: this file only marshals the module data that evolve3D reads and writes
-!! (SURVEY.md section 8b).
+!! material set-up, cosmology, output routines -- is the reference's own code, untouched: this file
+!! only marshals the module data that evolve3D reads and writes (SURVEY.md section 8b).
+!!
+!! Kept from the reference's evolve3D: the log lines ("Number of non-converged points", mean
+!! fractions, "Average number of subboxes"), the Timings.log stamps, the photon statistics line per
+!! global pass and per call (unit 90), the iteration dumps every 15 minutes of wall time
+!! (iterdump1.bin / iterdump2.bin, same record order) and the restart from such a dump.
 module evolve
 
   use precision, only: dp
   use clocks, only: timestamp_wallclock
-  use file_admin, only: logf, timefile
-  use my_mpi ! rank, npr
+  use file_admin, only: logf, timefile, iterdump, dump_dir
+  use my_mpi ! rank, npr, MPI_COMM_NEW
   use sizes, only: Ndim, mesh
   use grid, only: dr, vol
   use material, only: ndens, xh, xhe, temperature_grid, isothermal, temper_val, clumping
@@ -23,6 +28,7 @@ module evolve
   use radiation_tables, only: bb_heat_thick_table, bb_heat_thin_table, bb_FreqBnd_UpperLimit
   use cosmology, only: zred
   use cosmology_parameters, only: H0, Omega0
+  use c2ray_parameters, only: convergence_fraction
   use cgsconstants, only: arech0, brech0, areche0, breche0, oreche0, areche1, breche1, treche1
   use cgsconstants, only: colli_HI, colli_HeI, colli_HeII, v
   use photonstatistics, only: photon_loss, LLS_loss
@@ -47,6 +53,14 @@ module evolve
   integer,public :: sum_nbox_all
 
   logical :: tables_uploaded = .false.
+  !> number of H0, H+, He0, He+, He++ at the start of the time step (state_before)
+  real(kind=dp) :: n_before(5)
+  !> alternating dump file counter
+  integer :: ndump = 0
+
+#ifdef MPI
+  integer :: mympierror
+#endif
 
 contains
 
@@ -59,24 +73,16 @@ contains
     real(kind=dp),intent(in) :: dt !< time step
     integer,intent(in) :: restart !< restart flag
 
-    integer(c_int) :: niter
-    integer(c_int) :: conv_flags(512)
-    integer(c_int) :: nbox
-    integer :: n
+    integer :: niter
+    integer :: conv_flag
+    integer :: conv_criterion
+    integer(kind=8) :: wallclock1, wallclock2, countspersec
     integer(c_int) :: iso
     real(kind=dp) :: reccoef(12)
-    real(kind=dp) :: before(5), after(5), rates3(3)
+    real(kind=dp) :: n_after(5)
     type(c_ptr) :: tptr
 
-    if (restart /= 0) then
-       write(logf,*) "evolve3D (HIP): restart from an iteration dump is not available in this build"
-       stop 1
-    endif
-    if (npr > 1) then
-       write(logf,*) "evolve3D (HIP): multi-rank Fortran hosts must drive c2r_pass_sources / an ", &
-            "all-reduce / c2r_global_pass themselves (see INTEGRATION.md); npr = ", npr
-       stop 1
-    endif
+    call system_clock (wallclock1)
 
     if (.not. tables_uploaded) call upload_tables ()
 
@@ -98,67 +104,294 @@ contains
     if (.not.isothermal) tptr = c_loc_real4 (temperature_grid)
     call check (c2r_upload_state (hip_ctx, xh, xhe, tptr), "c2r_upload_state")
 
-    ! Initial state (for photon statistics): state_before (photonstatistics.f90:117-144), on the device
-    call check (c2r_state_sums (hip_ctx, 0_c_int, before), "c2r_state_sums")
+    ! Initial state (for photon statistics): state_before (photonstatistics.f90:117-144)
+    call check (c2r_state_sums (hip_ctx, 0_c_int, n_before), "c2r_state_sums")
+
+    if (restart == 0) then
+       ! xh_av = xh_intermed = xh, xhe_av = xhe_intermed = xhe
+       call check (c2r_begin_step (hip_ctx), "c2r_begin_step")
+       niter=0
+       conv_flag=mesh(1)*mesh(2)*mesh(3)
+    else
+       call start_from_dump (restart,niter)
+       call global_pass (conv_flag,dt)
+    endif
+
+    conv_criterion=min(int(convergence_fraction*mesh(1)*mesh(2)*mesh(3)),NumSrc)
 
     if (rank == 0) write(timefile,"(A,F8.1)") &
          "Time before starting iteration: ", timestamp_wallclock ()
 
-    ! --- the convergence loop of evolve.F90:154-222, on the device
-    call check (c2r_evolve3d (hip_ctx, dt, niter, conv_flags, 512_c_int), "c2r_evolve3d")
+    do
+       if (conv_flag < conv_criterion .and. niter > 1) then
+          ! xh = xh_intermed, xhe = xhe_intermed, set_final_temperature_point
+          call check (c2r_end_step (hip_ctx), "c2r_end_step")
+          if (rank == 0) then
+             write(logf,*) "Multiple sources convergence reached"
+             write(logf,*) "Test 1 values: ",conv_flag, conv_criterion
+          endif
+          exit
+       else
+          if (niter > 500) then
+             if (rank == 0) write(logf,*) 'Multiple sources not converging'
+             exit
+          endif
+       endif
+
+       niter=niter+1
+
+       call check (c2r_set_rates_to_zero (hip_ctx), "c2r_set_rates_to_zero")
+       LLS_loss = 0.0
+
+       if (NumSrc > 0) then
+          call pass_all_sources ()
+
+          if (rank == 0) then
+             write(logf,*) "Average number of subboxes: ", real(sum_nbox_all)/real(NumSrc)
+             call system_clock (wallclock2,countspersec)
+             write(logf,*) "Time and limit are: ", wallclock2-wallclock1, 15.0*60.0*countspersec
+             if (wallclock2-wallclock1 > 15*60*countspersec .or. wallclock2-wallclock1 < 0 ) then
+                call write_iteration_dump (niter)
+                wallclock1=wallclock2
+             endif
+          endif
+       endif
+
+       call global_pass (conv_flag,dt)
+
+       if (rank == 0) write(timefile,"(A,I3,A,F8.1)") &
+            "Time after iteration ",niter," : ", timestamp_wallclock ()
+    enddo
 
     ! --- results back to the modules that own them
     call check (c2r_download_state (hip_ctx, xh, xhe, tptr), "c2r_download_state")
-    call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
-         "c2r_download_rates")
-    ! xh_av, xhe_av, xh_intermed, xhe_intermed stay on the device: nothing outside the evolve chain
-    ! reads them (c2r_download_iter_state fetches them when a dump is wanted)
-    sum_nbox = nbox
-    sum_nbox_all = nbox
-    ! global_pass leaves the mean loss per cell in photonstatistics:photon_loss (evolve.F90:457)
-    photon_loss(:)=photon_loss_all(:)/(real(mesh(1))*real(mesh(2))*real(mesh(3)))
-    LLS_loss = 0.0
+    call download_rates ()
 
-    if (rank == 0) then
-       do n=1,niter
-          write(logf,*) "Number of non-converged points: ",conv_flags(n)
-       enddo
-       if (NumSrc > 0) write(logf,*) "Average number of subboxes: ", &
-            real(sum_nbox_all)/real(NumSrc)
-       if (niter <= 500) then
-          write(logf,*) "Multiple sources convergence reached"
-       else
-          write(logf,*) 'Multiple sources not converging'
-       endif
-       write(timefile,"(A,I3,A,F8.1)") &
-            "Time after iteration ",niter," : ", timestamp_wallclock ()
-    endif
-
-    ! The reference's global pass leaves the temperature-dependent coefficients of the last cell in the
-    ! module variables of cgsconstants (evolve_point.F90:543); photon statistics use them
-    if (.not.isothermal) then
-       call check (c2r_get_reccoef (hip_ctx, reccoef), "c2r_get_reccoef")
-       arech0=reccoef(1); brech0=reccoef(2); areche0=reccoef(3); breche0=reccoef(4)
-       oreche0=reccoef(5); areche1=reccoef(6); breche1=reccoef(7); treche1=reccoef(8)
-       colli_HI=reccoef(9); colli_HeI=reccoef(10); colli_HeII=reccoef(11); v=reccoef(12)
-    endif
-
-    ! Calculate photon statistics: calculate_photon_statistics (dt,xh,xh_av,xhe,xhe_av) of
-    ! evolve.F90:225 = state_after(xh,xhe) + total_rates(dt,xh_av,xhe_av) + total_ionizations, with
-    ! the grid reductions done on the device
-    call check (c2r_state_sums (hip_ctx, 0_c_int, after), "c2r_state_sums")
-    call check (c2r_total_rates (hip_ctx, dt, reccoef, rates3), "c2r_total_rates")
-    totrec=rates3(1)
-    totcollisions=rates3(2)
-    recomions=rates3(3)
-    dh0=before(1)-after(1)
-    dhe0=before(3)-after(3)
-    dhe2=after(5)-before(5)
-    total_ion=dh0+dhe0+dhe2
+    ! Calculate photon statistics: calculate_photon_statistics (dt,xh,xh_av,xhe,xhe_av)
+    call check (c2r_state_sums (hip_ctx, 0_c_int, n_after), "c2r_state_sums")
+    call photon_statistics (dt,n_after)
     call report_photonstatistics (dt)
     call update_grandtotal_photonstatistics (dt)
 
   end subroutine evolve3D
+
+  ! ===========================================================================
+
+  !> Ray trace the whole grid for all sources of this rank and sum over the ranks
+  subroutine pass_all_sources ()
+
+    integer(c_int) :: nbox
+    real(kind=dp) :: tail(NumFreqBnd)
+
+    if (rank == 0) write(logf,*) 'Doing all sources '
+
+    ! static distribution of the sources over the ranks: ns = 1+rank, NumSrc, npr
+    ! (do_grid_static, master_slave.F90:74-96)
+    call check (c2r_pass_sources (hip_ctx, int(1+rank,c_int), int(npr,c_int)), "c2r_pass_sources")
+
+#ifdef MPI
+    ! mpi_accumulate_grid_quantities (evolve.F90:505-548) through host staging buffers
+    call download_rates ()
+    call mpi_sum_in_place (phih_grid, size(phih_grid))
+    call mpi_sum_in_place (phihe_grid, size(phihe_grid))
+    if (.not.isothermal) call mpi_sum_in_place (phiheat, size(phiheat))
+    call mpi_sum_in_place (photon_loss_all, NumFreqBnd)
+    call MPI_ALLREDUCE (sum_nbox, sum_nbox_all, 1, MPI_INTEGER, MPI_SUM, MPI_COMM_NEW, mympierror)
+    call check (c2r_upload_rates (hip_ctx, phih_grid, phihe_grid, phiheat), "c2r_upload_rates")
+#else
+    call check (c2r_get_loss (hip_ctx, tail, nbox), "c2r_get_loss")
+    photon_loss_all(:)=tail(:)
+    sum_nbox=nbox
+    sum_nbox_all=nbox
+#endif
+
+  end subroutine pass_all_sources
+
+  ! ===========================================================================
+
+  !> Apply the rates: one chemistry pass over the whole grid, report on convergence
+  subroutine global_pass (conv_flag,dt)
+
+    integer,intent(out) :: conv_flag
+    real(kind=dp),intent(in) :: dt
+
+    integer(c_int) :: cf
+    real(kind=dp) :: means(5), n_now(5)
+
+    ! mean photon loss per cell (evolve.F90:457)
+    photon_loss(:)=photon_loss_all(:)/(real(mesh(1))*real(mesh(2))*real(mesh(3)))
+
+    if (rank == 0) write(logf,*) 'Doing global '
+    call check (c2r_global_pass (hip_ctx, dt, cf), "c2r_global_pass")
+    conv_flag=cf
+
+    if (rank == 0) then
+       call check (c2r_fraction_means (hip_ctx, 1_c_int, means), "c2r_fraction_means")
+       write(logf,*) "Number of non-converged points: ",conv_flag
+       write(logf,*) "Intermediate result for mean H ionization fraction: ", means(2)
+       write(logf,*) "Intermediate result for mean He(+,++) ionization fraction: ", means(4), means(5)
+    endif
+
+    ! photon conservation: calculate_photon_statistics (dt,xh_intermed,xh_av,xhe_intermed,xhe_av)
+    call check (c2r_state_sums (hip_ctx, 1_c_int, n_now), "c2r_state_sums")
+    call photon_statistics (dt,n_now)
+    call report_photonstatistics (dt)
+
+  end subroutine global_pass
+
+  ! ===========================================================================
+
+  !> total_rates + total_ionizations of photonstatistics.f90 with the grid sums from the device
+  subroutine photon_statistics (dt,n_after)
+
+    real(kind=dp),intent(in) :: dt
+    real(kind=dp),intent(in) :: n_after(5)
+
+    real(kind=dp) :: reccoef(12), rates3(3)
+
+    ! The reference's global pass leaves the temperature-dependent coefficients of the last cell in the
+    ! module variables of cgsconstants (evolve_point.F90:543); total_rates uses them
+    call check (c2r_get_reccoef (hip_ctx, reccoef), "c2r_get_reccoef")
+    if (.not.isothermal) then
+       arech0=reccoef(1); brech0=reccoef(2); areche0=reccoef(3); breche0=reccoef(4)
+       oreche0=reccoef(5); areche1=reccoef(6); breche1=reccoef(7); treche1=reccoef(8)
+       colli_HI=reccoef(9); colli_HeI=reccoef(10); colli_HeII=reccoef(11); v=reccoef(12)
+    endif
+    call check (c2r_total_rates (hip_ctx, dt, reccoef, rates3), "c2r_total_rates")
+    totrec=rates3(1)
+    totcollisions=rates3(2)
+    recomions=rates3(3)
+    dh0=n_before(1)-n_after(1)
+    dhe0=n_before(3)-n_after(3)
+    dhe2=n_after(5)-n_before(5)
+    total_ion=dh0+dhe0+dhe2
+
+  end subroutine photon_statistics
+
+  ! ===========================================================================
+
+  !> phih_grid, phihe_grid, phiheat, photon_loss_all, sum_nbox to their host mirrors
+  subroutine download_rates ()
+
+    integer(c_int) :: nbox
+
+    call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
+         "c2r_download_rates")
+    sum_nbox=nbox
+#ifndef MPI
+    sum_nbox_all=nbox
+#endif
+
+  end subroutine download_rates
+
+  ! ===========================================================================
+
+  !> Same content and record order as the reference's dump (evolve.F90:233-275), so either code can
+  !! restart from the other's file
+  subroutine write_iteration_dump (niter)
+
+    integer,intent(in) :: niter
+    character(len=20) :: iterfile
+    type(c_ptr) :: tptr
+
+    write(timefile,"(A,F8.1)") "Time before writing iterdump: ", timestamp_wallclock ()
+
+    call download_rates ()
+    call check (c2r_download_iter_state (hip_ctx, xh_av, xhe_av, xh_intermed, xhe_intermed), &
+         "c2r_download_iter_state")
+    if (.not.isothermal) then
+       tptr = c_loc_real4 (temperature_grid)
+       ! (xh, xhe on the device are still the start-of-step values the host holds)
+       call check (c2r_download_state (hip_ctx, xh, xhe, tptr), "c2r_download_state")
+    endif
+
+    ndump=ndump+1
+    if (mod(ndump,2) == 0) then
+       iterfile="iterdump2.bin"
+    else
+       iterfile="iterdump1.bin"
+    endif
+    open(unit=iterdump,file=trim(adjustl(dump_dir))//iterfile,form="unformatted",status="unknown")
+    write(iterdump) niter
+    write(iterdump) photon_loss_all
+    write(iterdump) phih_grid
+    write(iterdump) xh_av
+    write(iterdump) xh_intermed
+    write(iterdump) phihe_grid
+    write(iterdump) xhe_av
+    write(iterdump) xhe_intermed
+    if (.not.isothermal) then
+       write(iterdump) phiheat
+       write(iterdump) temperature_grid
+    endif
+    close(iterdump)
+
+    write(timefile,"(A,F8.1)") "Time after writing iterdump: ", timestamp_wallclock ()
+
+  end subroutine write_iteration_dump
+
+  ! ===========================================================================
+
+  !> Reload the iteration state of a dump (evolve.F90:279-367) and put it on the device
+  subroutine start_from_dump (restart,niter)
+
+    integer,intent(in) :: restart
+    integer,intent(out) :: niter
+    character(len=20) :: iterfile
+    type(c_ptr) :: tptr
+
+    niter=0
+    if (rank == 0) then
+       write(timefile,"(A,F8.1)") "Time before reading iterdump: ", timestamp_wallclock ()
+       select case (restart)
+       case (1)
+          iterfile="iterdump1.bin"
+       case (2)
+          iterfile="iterdump2.bin"
+       case default
+          iterfile="iterdump.bin"
+       end select
+       open(unit=iterdump,file=trim(adjustl(dump_dir))//iterfile,form="unformatted",status="old")
+       read(iterdump) niter
+       read(iterdump) photon_loss_all
+       read(iterdump) phih_grid
+       read(iterdump) xh_av
+       read(iterdump) xh_intermed
+       read(iterdump) phihe_grid
+       read(iterdump) xhe_av
+       read(iterdump) xhe_intermed
+       if (.not.isothermal) then
+          read(iterdump) phiheat
+          read(iterdump) temperature_grid
+       endif
+       close(iterdump)
+       write(logf,*) "Read iteration ",niter," from dump file"
+       write(logf,*) 'photon loss counter: ',photon_loss_all
+    endif
+#ifdef MPI
+    call MPI_BCAST (niter,1,MPI_INTEGER,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (photon_loss_all,NumFreqBnd,MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (phih_grid,size(phih_grid),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (phihe_grid,size(phihe_grid),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (xh_av,size(xh_av),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (xhe_av,size(xhe_av),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (xh_intermed,size(xh_intermed),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    call MPI_BCAST (xhe_intermed,size(xhe_intermed),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+    if (.not.isothermal) then
+       call MPI_BCAST (phiheat,size(phiheat),MPI_DOUBLE_PRECISION,0,MPI_COMM_NEW,mympierror)
+       call MPI_BCAST (temperature_grid,size(temperature_grid),MPI_REAL,0,MPI_COMM_NEW,mympierror)
+    endif
+#endif
+    call check (c2r_upload_rates (hip_ctx, phih_grid, phihe_grid, phiheat), "c2r_upload_rates")
+    call check (c2r_upload_iter_state (hip_ctx, xh_av, xhe_av, xh_intermed, xhe_intermed), &
+         "c2r_upload_iter_state")
+    if (.not.isothermal) then
+       tptr = c_loc_real4 (temperature_grid)
+       call check (c2r_upload_state (hip_ctx, xh, xhe, tptr), "c2r_upload_state")
+    endif
+    if (rank == 0) write(timefile,"(A,F8.1)") "Time after reading iterdump: ", timestamp_wallclock ()
+
+  end subroutine start_from_dump
 
   ! ===========================================================================
 
@@ -229,6 +462,20 @@ contains
     enddo
 
   end subroutine read_cooling_tables
+
+  ! ===========================================================================
+
+#ifdef MPI
+  subroutine mpi_sum_in_place (a, n)
+    integer,intent(in) :: n
+    real(kind=dp),intent(inout) :: a(n)
+    real(kind=dp),allocatable :: buffer(:)
+    allocate(buffer(n))
+    call MPI_ALLREDUCE (a, buffer, n, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_NEW, mympierror)
+    a(:)=buffer(:)
+    deallocate(buffer)
+  end subroutine mpi_sum_in_place
+#endif
 
   ! ===========================================================================
 

@@ -95,6 +95,9 @@ int c2r_end_step(c2r_ctx *ctx);
  * evolve.F90:457); evolve_source: sum_nbox.  Any pointer may be NULL. */
 int c2r_download_rates(c2r_ctx *ctx, double *phih, double *phihe, double *phiheat,
                        double *photon_loss47, int *sum_nbox);
+/* photon_loss(1:47) and sum_nbox of this rank's sources since the last c2r_set_rates_to_zero, from
+ * the host-side bookkeeping (no device copy). */
+int c2r_get_loss(c2r_ctx *ctx, double *photon_loss47, int *sum_nbox);
 /* evolve_data: xh_av, xhe_av, xh_intermed, xhe_intermed -- the iteration-dump content
  * (write_iteration_dump, evolve.F90:233-275). */
 int c2r_download_iter_state(c2r_ctx *ctx, double *xh_av, double *xhe_av, double *xh_intermed,
@@ -121,6 +124,9 @@ int c2r_download_columns(c2r_ctx *ctx, double *coldensh_out, double *coldenshe_o
  * The sums are deterministic but associate differently from the reference's serial loops: they agree
  * with it to rounding, not bit for bit. */
 int c2r_state_sums(c2r_ctx *ctx, int which, double out5[5]);
+/* sum(x(:,:,:,n))/mesh^3 for the five fractions of `which` -- the "Intermediate result for mean
+ * ... ionization fraction" lines of global_pass (evolve.F90:489-494) */
+int c2r_fraction_means(c2r_ctx *ctx, int which, double out5[5]);
 int c2r_total_rates(c2r_ctx *ctx, double dt, const double reccoef[12], double out3[3]);
 int c2r_get_reccoef(c2r_ctx *ctx, double out12[12]);
 

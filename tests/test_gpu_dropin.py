@@ -40,10 +40,11 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, sources):
     a = (r1 / "results" / "PhotonCounts2.out").read_text().split()
     b = (r2 / "results" / "PhotonCounts2.out").read_text().split()
     assert a == b
-    # PhotonCounts.out (unit 90, report_photonstatistics): the reference writes a line per global pass
-    # plus one per evolve3D call; the HIP shim writes the per-call line, from grid sums reduced on
-    # the device (a different summation order: equal to the printed 4 digits, up to a last-digit flip)
+    # PhotonCounts.out (unit 90, report_photonstatistics): one line per global pass plus one per
+    # evolve3D call, in both runs; the HIP shim fills it from grid sums reduced on the device (a
+    # different summation order: equal to the printed 4 digits, up to a last-digit flip)
     import numpy as np
+
     def numbers(path):
         rows = []
         for line in path.read_text().splitlines():
@@ -58,7 +59,8 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, sources):
     pa = numbers(r1 / "results" / "PhotonCounts.out")
     pb = numbers(r2 / "results" / "PhotonCounts.out")
     calls = refrun.parse_log(r1)
-    idx = np.cumsum([len(c) + 1 for c in calls]) - 1      # last line of each call in the reference file
-    assert pb.shape[0] == len(calls)
-    ref_lines = pa[idx]
-    assert np.allclose(pb, ref_lines, rtol=2.5e-3, atol=0), (pb, ref_lines)
+    assert pa.shape == pb.shape and pa.shape[0] == sum(len(c) + 1 for c in calls)
+    # columns: total_ion, totalsrc, recomions, photon_loss, totrec, totcollisions, 3 ratios.  total_ion
+    # is a difference of two large sums (before - after), so compare it relative to the source term
+    scale = np.maximum(np.abs(pa), np.abs(pa[:, 1:2]) * 1e-3)
+    assert np.all(np.abs(pb - pa) <= 2.5e-3 * scale), np.max(np.abs(pb - pa) / scale)

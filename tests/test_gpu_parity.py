@@ -366,3 +366,64 @@ def test_non_cubic_mesh_vs_oracle(pkg, orc, otables, tables, mesh, iso):
     assert r["sum_nbox"] == s.c.sum_nbox
     cols = ev.engine.download_columns()
     assert np.array_equal(cols["coldensh_out"], s.coldensh_out)
+
+
+def test_iteration_dump_and_restart_through_the_cabi(pkg, tables, gold):
+    """What write_iteration_dump / start_from_dump (evolve.F90:233-367) need from the library: stop an
+    evolve3D after k outer iterations, take the dump content off the device, put it into a FRESH
+    context (start_from_dump + global_pass, evolve.F90:138-140) and finish: bit-identical to the
+    uninterrupted call, same total iteration count."""
+    i, o = tap_case(gold("tap_N16_heat_3src.npz"), 1)
+    mesh, mat, grid, src, cosmo = make_inputs(pkg, i)
+    dt = float(i["dt"][0])
+    nsrc = src.NumSrc
+    crit = min(int(pkg.evolve.convergence_fraction * mesh[0] * mesh[1] * mesh[2]), nsrc)
+
+    def loop(e, niter, conv):
+        while True:
+            if conv < crit and niter > 1:
+                e.end_step()
+                return niter
+            niter += 1
+            e.set_rates_to_zero()
+            e.pass_sources(1, 1)
+            conv = e.global_pass(dt)
+            if niter == 7 and stop_at_7[0]:
+                return niter
+
+    stop_at_7 = [True]
+    e1 = engine_for(pkg, mesh, mat, grid, src, cosmo, tables)
+    e1.begin_step()
+    assert loop(e1, 0, int(np.prod(mesh))) == 7
+    # dump content: the rates of iteration 7 *before* its global pass are what the reference writes;
+    # restarting re-runs that global pass, so take the state as it was before it.  Re-create it:
+    e1.close()
+    e1 = engine_for(pkg, mesh, mat, grid, src, cosmo, tables)
+    e1.begin_step()
+    n = 0
+    conv = int(np.prod(mesh))
+    for n in range(1, 8):
+        e1.set_rates_to_zero()
+        e1.pass_sources(1, 1)
+        if n < 7:
+            conv = e1.global_pass(dt)
+    dump = {**e1.download_rates(), **e1.download_iter_state()}
+    m1 = pkg.Material(ndens=mat.ndens, xh=mat.xh, xhe=mat.xhe, temperature_grid=mat.temperature_grid)
+    e1.download_state(m1)
+    e1.close()
+
+    # fresh context: start_from_dump, then global_pass, then the loop continues from niter = 7
+    mat2 = pkg.Material(mat.ndens, mat.xh.copy(), mat.xhe.copy(), m1.temperature_grid, False, mat.temper_val,
+                        mat.clumping, mat.reccoef)
+    e2 = engine_for(pkg, mesh, mat2, grid, src, cosmo, tables)
+    e2.upload_rates(dump["phih_grid"], dump["phihe_grid"], dump["phiheat"])
+    e2.upload_iter_state(dump["xh_av"], dump["xhe_av"], dump["xh_intermed"], dump["xhe_intermed"])
+    conv = e2.global_pass(dt)
+    stop_at_7[0] = False
+    niter = loop(e2, 7, conv)
+    assert niter == len(o["conv_flags"])
+    out = pkg.Material(ndens=mat.ndens, xh=mat.xh, xhe=mat.xhe, temperature_grid=mat.temperature_grid)
+    e2.download_state(out)
+    assert np.array_equal(out.xh, o["xh"]) and np.array_equal(out.xhe, o["xhe"])
+    assert np.array_equal(out.temperature_grid, o["temperature"])
+    e2.close()
