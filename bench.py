@@ -44,7 +44,7 @@ def measured_traffic(kernel):
         return None
 
 
-def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0):
+def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False):
     """Synthetic inputs of BASELINE configs[2]: uniform density of the
     reference's test problem at z = 9, isothermal 1e4 K, sources at seeded positions
     (numpy default_rng(12345), integers in [1, n]) of 1e56 photons/s each.  The gas starts highly
@@ -61,7 +61,8 @@ def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0):
     x0 = 1.0e-3 * (1.0 + 0.5 * np.sin(np.arange(nc, dtype=np.float64) * 1.0e-3))  # neutral fraction
     xh = np.concatenate([x0, 1.0 - x0])
     xhe = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
-    mat = pkg.Material(ndens, xh, xhe, None, True, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    temp = np.full(3 * nc, 1.0e4, dtype=np.float32) if heating else None
+    mat = pkg.Material(ndens, xh, xhe, temp, not heating, 1.0e4, 1.0, hp.reccoef(1.0e4))
     grid = pkg.GridProps((n, n, n), dr, vol)
     src = pkg.SourceProps(srcpos, np.full(nsrc, 1.0e56 / 1.0e48), 1.0e48)
     cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
@@ -133,6 +134,8 @@ def main():
     ap.add_argument("--sources", type=int, default=8, help="sources per GPU")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--heating", action="store_true",
+                    help="non-isothermal variant (heating tables, thermal evolution); not the headline config")
     a = ap.parse_args()
 
     import torch
@@ -153,7 +156,7 @@ def main():
     n = a.mesh
     total_src = a.sources * world
     # every rank holds the full source list; rank r sweeps r+1, r+1+world, ... (master_slave.F90:85)
-    mat, grid, src, cosmo = config3_inputs(pkg, n, total_src)
+    mat, grid, src, cosmo = config3_inputs(pkg, n, total_src, heating=a.heating)
     tables = pkg.RadiationTables.load()
     e = pkg.HipEngine((n, n, n), local)
     e.set_tables(tables)
@@ -217,8 +220,9 @@ def main():
             "value": units / elapsed, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: {n}^3 uniform density, {a.sources} sources per GPU "
-                                   f"({total_src} total), isothermal 1e4 K, one evolve3D outer iteration per step",
+            "config": {"workload": f"{'BASELINE configs[2]' if n == 256 and not a.heating else 'variant of BASELINE configs[2]'}: {n}^3 uniform density, {a.sources} sources per GPU "
+                                   f"({total_src} total), {'heating + thermal evolution' if a.heating else 'isothermal 1e4 K'}, "
+                                   f"one evolve3D outer iteration per step",
                        "mesh": n, "sources_per_gpu": a.sources, "batch": a.batch, "coverage": coverage,
                        "parallelism": f"sources over {world} GPU(s), all-reduce of rate grids, replicated chemistry"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -597,6 +598,11 @@ struct c2r_ctx {
   std::vector<hipEvent_t> ev_pool; // timing events, grown on demand
   size_t ev_used = 0;
 
+  // LDS bytes requested (not used) by each rates block: caps the rates kernel at
+  // floor(160 KiB / rates_lds) blocks per CU so that waves of the next batch's column sweep can be
+  // co-resident on the same SIMDs (the sweep is memory-bound, the rates kernel ALU-bound)
+  unsigned rates_lds = 0;
+
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   c2r_timing tm{};
@@ -683,6 +689,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMemset(c->d_rc_last, 0, sizeof(double) * 12));
   CR(hipMalloc(&c->d_stat, sizeof(double) * (STAT_BLOCKS * 5 + 8)));
   CR(hipHostMalloc(&c->h_stat, sizeof(double) * 8));
+  if (const char *e = getenv("C2R_RATES_LDS")) c->rates_lds = (unsigned)atoi(e);
   c->rates_count = 4 * nc + C2R_NFREQ + 1;
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
@@ -1076,11 +1083,11 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
     if (c->timing) HIPCHK(c, hipEventRecord(e_r0, c->stream2));
     const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
     if (c->isothermal)
-      hipLaunchKernelGGL(k_rates<false>, dim3(nblk), dim3(BLOCK), 0, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
+      hipLaunchKernelGGL(k_rates<false>, dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
                          c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
                          c->d_heat_thin, c->d_rates);
     else
-      hipLaunchKernelGGL(k_rates<true>, dim3(nblk), dim3(BLOCK), 0, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
+      hipLaunchKernelGGL(k_rates<true>, dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
                          c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
                          c->d_heat_thin, c->d_rates);
     HIPCHK(c, hipGetLastError());
