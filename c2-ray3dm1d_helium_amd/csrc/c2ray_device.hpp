@@ -608,6 +608,228 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// The -DPL / -DQUASARS builds of the reference add up to two more SEDs per source (power law,
+// quasar-like; radiation_photoionrates.f90:215-228, :256-271): the same band loop with that SED's
+// tables, flux and band range [Minimum_FreqBnd, Maximum_FreqBnd], each lookuptable call starting
+// its sums from zero, the results added to phi in the order photo BB, PL, QPL, heat BB, PL, QPL.
+constexpr int NSED = 3;
+struct SedSet {
+  const double *photo_thick[NSED], *photo_thin[NSED], *heat_thick[NSED], *heat_thin[NSED];
+  int lo[NSED], hi[NSED]; // 0-based first band, one past the last band; lo == hi: SED absent
+};
+
+template <bool HEAT>
+C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
+                                 double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
+                                 double i_state, PhotoOut &o) {
+  o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
+  o.heat = 0.0;
+  o.photo_out = 0.0;
+  bool act[NSED];
+  int blo = NFREQ, bhi = 0;
+  for (int s = 0; s < NSED; s++) {
+    act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
+    if (act[s]) { blo = ss.lo[s] < blo ? ss.lo[s] : blo; bhi = ss.hi[s] > bhi ? ss.hi[s] : bhi; }
+  }
+  if (bhi <= blo) return;
+  const Recip rvol = make_recip(vol);
+  const double cell_HI = cout_HI - cin_HI;
+  const double cell_HeI = cout_HeI - cin_HeI;
+  const double cell_HeII = cout_HeII - cin_HeII;
+  double P_HI[NSED] = {0, 0, 0}, P_HeI[NSED] = {0, 0, 0}, P_HeII[NSED] = {0, 0, 0}, P_out[NSED] = {0, 0, 0};
+  double f_heat[NSED] = {0, 0, 0}, f_ion_HI[NSED] = {0, 0, 0}, f_ion_HeI[NSED] = {0, 0, 0};
+  double df_ion_HI[NSED] = {0, 0, 0}, df_ion_HeI[NSED] = {0, 0, 0};
+  double y1R[3], y2R[3];
+  if (HEAT) {
+    const double CR1[3] = {0.3908, 0.0554, 1.0}, bR1[3] = {0.4092, 0.4614, 0.2663},
+                 dR1[3] = {1.7592, 1.6660, 1.3163};
+    const double CR2[3] = {0.6941, 0.0984, 3.9811}, aR2[3] = {0.2, 0.2, 0.4}, bR2[3] = {0.38, 0.38, 0.34};
+    for (int i = 0; i < 3; i++) {
+      y1R[i] = CR1[i] * C2R_MATH_POW(1.0 - C2R_MATH_POW(i_state, bR1[i]), dR1[i]);
+      double xeb = 1.0 - C2R_MATH_POW(i_state, bR2[i]);
+      y2R[i] = CR2[i] * C2R_MATH_POW(i_state, aR2[i]) * xeb * xeb;
+    }
+  }
+  for (int b = blo; b < bhi; b++) {
+    bool any = false;
+    for (int s = 0; s < NSED; s++) any = any || (act[s] && b >= ss.lo[s] && b < ss.hi[s]);
+    if (!any) continue;
+    const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
+    const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+    const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
+    const TauPos pin = tau_table_position(tau_in);
+    const double dtau = tau_out - tau_in;
+    const bool thick = fabs(dtau) > tau_photo_limit;
+    const bool hthick = fabs(dtau) > tau_heat_limit;
+    TauPos pout;
+    if (thick || (HEAT && hthick)) pout = tau_table_position(tau_out);
+    else { pout.ipos = 0; pout.residual = 0.0; }
+    double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
+    if (b >= NB1 && b < NB1 + NB2) {
+      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI);
+      sc_HI = sHI * cell_HI * forscaleing;
+      sc_HeI = sHeI * cell_HeI * forscaleing;
+    } else if (b >= NB1 + NB2) {
+      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
+      sc_HI = cell_HI * sHI * forscaleing;
+      sc_HeI = cell_HeI * sHeI * forscaleing;
+      sc_HeII = cell_HeII * sHeII * forscaleing;
+    }
+    for (int s = 0; s < NSED; s++) {
+      if (!(act[s] && b >= ss.lo[s] && b < ss.hi[s])) continue;
+      const double NF = NFlux[s];
+      {
+        const double *tk = ss.photo_thick[s] + (size_t)b * NTAUP;
+        double phi_in = NF * read_table(tk, pin);
+        double phi_out, phi_all;
+        if (thick) {
+          phi_out = NF * read_table(tk, pout);
+          phi_all = phi_in - phi_out;
+        } else {
+          phi_all = NF * dtau * read_table(ss.photo_thin[s] + (size_t)b * NTAUP, pin);
+          phi_out = phi_in - phi_all;
+        }
+        P_out[s] = P_out[s] + phi_out;
+        if (b < NB1) {
+          P_HI[s] = P_HI[s] + div_recip(phi_all, rvol);
+        } else if (b < NB1 + NB2) {
+          P_HI[s] = P_HI[s] + div_recip(sc_HI * phi_all, rvol);
+          P_HeI[s] = P_HeI[s] + div_recip(sc_HeI * phi_all, rvol);
+        } else {
+          P_HI[s] = P_HI[s] + div_recip(sc_HI * phi_all, rvol);
+          P_HeI[s] = P_HeI[s] + div_recip(sc_HeI * phi_all, rvol);
+          P_HeII[s] = P_HeII[s] + div_recip(sc_HeII * phi_all, rvol);
+        }
+      }
+      if (HEAT) {
+        double df_heat;
+        const double *HT = ss.heat_thick[s], *HN = ss.heat_thin[s];
+        if (b < NB1) {
+          const double *tk = HT + (size_t)b * NTAUP;
+          double in_HI = NF * read_table(tk, pin);
+          double h_HI;
+          if (hthick) {
+            double out_HI = NF * read_table(tk, pout);
+            h_HI = div_recip(in_HI - out_HI, rvol);
+          } else {
+            h_HI = NF * (cell_HI * sHI) * read_table(HN + (size_t)b * NTAUP, pin);
+            h_HI = div_recip(h_HI, rvol);
+          }
+          df_heat = h_HI;
+        } else if (b < NB1 + NB2) {
+          const int cH = 2 * (b + 1) - NB1 - 1 - 1;
+          const double *tkH = HT + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP;
+          double in_HI = NF * read_table(tkH, pin);
+          double in_HeI = NF * read_table(tkHe, pin);
+          double h_HI, h_HeI;
+          if (hthick) {
+            double out_HI = NF * read_table(tkH, pout);
+            h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
+            double out_HeI = NF * read_table(tkHe, pout);
+            h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
+          } else {
+            const double *tnH = HN + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
+            h_HI = NF * (cell_HI * sHI) * read_table(tnH, pin);
+            h_HI = div_recip(h_HI, rvol);
+            h_HeI = NF * (cell_HeI * sHeI) * read_table(tnHe, pin);
+            h_HeI = div_recip(h_HeI, rvol);
+          }
+          df_heat = h_HI + h_HeI;
+          const int q = b - 1;
+          double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI;
+          double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
+          double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
+          double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
+          df_ion_HeI[s] = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
+          df_ion_HI[s] = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
+          df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+        } else {
+          const int cH = 3 * (b + 1) - NB2 - NB1 * 2 - 2 - 1;
+          const double *tkH = HT + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP, *tkHe2 = tkHe + NTAUP;
+          double in_HI = NF * read_table(tkH, pin);
+          double in_HeI = NF * read_table(tkHe, pin);
+          double in_HeII = NF * read_table(tkHe2, pin);
+          double h_HI, h_HeI, h_HeII;
+          if (hthick) {
+            double out_HI = NF * read_table(tkH, pout);
+            h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
+            double out_HeI = NF * read_table(tkHe, pout);
+            h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
+            double out_HeII = NF * read_table(tkHe2, pout);
+            h_HeII = div_recip(sc_HeII * (in_HeII - out_HeII), rvol);
+          } else {
+            const double *tnH = HN + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
+            h_HI = NF * (cell_HI * sHI) * read_table(tnH, pin);
+            h_HI = div_recip(h_HI, rvol);
+            h_HeI = NF * (cell_HeI * sHeI) * read_table(tnHe, pin);
+            h_HeI = div_recip(h_HeI, rvol);
+            h_HeII = NF * (cell_HeII * sHeII) * read_table(tnHe2, pin);
+            h_HeII = div_recip(h_HeII, rvol);
+          }
+          df_heat = h_HI + h_HeI + h_HeII;
+          const int q = b - 1;
+          double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI + bd.f1ion_HeII[q] * h_HeII;
+          double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
+          double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
+          double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
+          df_ion_HeI[s] = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
+          df_ion_HI[s] = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
+          df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+        }
+        f_heat[s] = f_heat[s] + df_heat;
+        f_ion_HI[s] = f_ion_HI[s] + df_ion_HI[s];
+        f_ion_HeI[s] = f_ion_HeI[s] + df_ion_HeI[s];
+      }
+    }
+  }
+  // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
+  for (int s = 0; s < NSED; s++) {
+    if (!act[s]) continue;
+    o.photo_HI = o.photo_HI + P_HI[s];
+    o.photo_HeI = o.photo_HeI + P_HeI[s];
+    o.photo_HeII = o.photo_HeII + P_HeII[s];
+    o.photo_out = o.photo_out + P_out[s];
+  }
+  if (HEAT) {
+    for (int s = 0; s < NSED; s++) {
+      if (!act[s]) continue;
+      o.heat = o.heat + f_heat[s];
+      o.photo_HI = o.photo_HI + f_ion_HI[s] / (ion_freq_HI * hplanck);
+      o.photo_HeI = o.photo_HeI + f_ion_HeI[s] / (ion_freq_HeI * hplanck);
+    }
+  }
+}
+
+// photo_out of all SEDs (boundary photon loss), one table position per band as in photo_out_only
+C2R_HD double photo_out_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
+                              double cout_HeI, double cin_HeII, double cout_HeII, const double *NFlux) {
+  double total = 0.0;
+  for (int s = 0; s < NSED; s++) {
+    if (!(NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s])) continue;
+    double photo_out = 0.0;
+    for (int b = ss.lo[s]; b < ss.hi[s]; b++) {
+      const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
+      const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+      const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
+      const double *tk = ss.photo_thick[s] + (size_t)b * NTAUP;
+      double phi_out;
+      if (fabs(tau_out - tau_in) > tau_photo_limit) {
+        const TauPos pout = tau_table_position(tau_out);
+        phi_out = NFlux[s] * read_table(tk, pout);
+      } else {
+        const TauPos pin = tau_table_position(tau_in);
+        double phi_in = NFlux[s] * read_table(tk, pin);
+        double phi_all = NFlux[s] * (tau_out - tau_in) * read_table(ss.photo_thin[s] + (size_t)b * NTAUP, pin);
+        phi_out = phi_in - phi_all;
+      }
+      photo_out = photo_out + phi_out;
+    }
+    total = total + photo_out;
+  }
+  return total;
+}
+
 // photo_out only (the quantity evolve0D adds to the photon loss of boundary cells,
 // evolve_point.F90:310-315): the band loop of photo_lookuptable reduced to phi_photo_out_all.
 // An optically thick band needs only the table position of tau_out (phi_out = NFlux*T(tau_out));

@@ -42,11 +42,13 @@ struct SrcInfo {
   int i0, j0, k0;      // 1-based mesh position (srcpos)
   int lo[3], hi[3];    // current sub-box, as offsets last_l - srcpos, last_r - srcpos
   double nflux;        // NormFlux(ns)
+  double nflux_sed[2]; // NormFluxPL(ns), NormFluxQPL(ns) (-DPL / -DQUASARS builds), else 0
   int slot;            // scratch slot
   int pad;
 };
 struct BatchArgs {
   int n;
+  int multi;           // some source of the run has a power-law / quasar SED
   SrcInfo s[MAXB];
 };
 
@@ -169,8 +171,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__restrict__ ndens,
               const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
               const double *__restrict__ stateT, double *__restrict__ col,
-              const BandData *__restrict__ bd, const double *__restrict__ photo_thick,
-              const double *__restrict__ photo_thin, double *__restrict__ loss_partial, int blocks_total,
+              const BandData *__restrict__ bd, SedSet ss, double *__restrict__ loss_partial, int blocks_total,
               int block_base) {
   __shared__ double sh[BLOCK / 64];
   const SrcInfo &S = ba.s[blockIdx.y];
@@ -235,8 +236,14 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
       const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
                             dk == S.hi[2];
       if (boundary && cin_HI < max_coldensh) {
-        const double po = photo_out_only(*bd, photo_thick, photo_thin, cin_HI, cout_HI, cin_HeI, cout_HeI,
-                                         cin_HeII, cout_HeII, S.nflux);
+        double po;
+        if (ba.multi) {
+          const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+          po = photo_out_multi(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, nf);
+        } else {
+          po = photo_out_only(*bd, ss.photo_thick[0], ss.photo_thin[0], cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII,
+                              cout_HeII, S.nflux);
+        }
         loss = po * sc.vol / vol_ph;
       }
     }
@@ -285,12 +292,11 @@ __device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
 // Rates of every cell from every source of the batch, accumulated in source order
 // (evolve_point.F90:246-306 with photoion_rates, radiation_photoionrates.f90:108-277).
 // rates layout: [phih | phihe0 | phihe1 | phiheat] each ncell.
-template <bool HEAT>
-__global__ void __launch_bounds__(BLOCK, HEAT ? 3 : 5)
+template <bool HEAT, bool MULTI>
+__global__ void __launch_bounds__(BLOCK, MULTI ? 2 : (HEAT ? 3 : 5))
 k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
         const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
-        const double *__restrict__ photo_thick, const double *__restrict__ photo_thin,
-        const double *__restrict__ heat_thick, const double *__restrict__ heat_thin, double *__restrict__ rates) {
+        SedSet ss, double *__restrict__ rates) {
   const size_t nc = g.ncell;
   const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (q >= nc) return;
@@ -330,8 +336,13 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
     }
     if (cin_HI < max_coldensh) {
       PhotoOut o;
-      photoion_rates<HEAT>(*bd, photo_thick, photo_thin, heat_thick, heat_thin, cin_HI, cout_HI, cin_HeI, cout_HeI,
-                           cin_HeII, cout_HeII, vol_ph, S.nflux, h1, o);
+      if (MULTI) {
+        const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, h1, o);
+      } else {
+        photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
+                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, h1, o);
+      }
       a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
       a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);
       a_HeII = a_HeII + o.photo_HeII / (he1 * nd * abu_he);
@@ -547,6 +558,7 @@ struct c2r_ctx {
   double *d_photo_thick = nullptr, *d_photo_thin = nullptr, *d_heat_thick = nullptr, *d_heat_thin = nullptr;
   BandData *d_bands = nullptr;
   bool have_tables = false, have_heat_tables = false;
+  int bb_upper = 0;
   double *d_cool = nullptr;
   bool have_cool = false;
   double cool_mintemp = 1.0, cool_dtemp = 0.01;
@@ -561,6 +573,12 @@ struct c2r_ctx {
   std::vector<int> srcpos;
   std::vector<double> normflux;
   double s_star = 0;
+  // -DPL / -DQUASARS: power-law (0) and quasar-like (1) SEDs
+  double *d_sed_tab[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  int sed_lo[2] = {0, 0}, sed_hi[2] = {0, 0}; // 0-based [lo, hi)
+  bool have_sed[2] = {false, false}, have_sed_heat[2] = {false, false};
+  std::vector<double> normflux_sed[2];
+  double s_star_sed[2] = {0, 0};
 
   double *d_xh = nullptr, *d_xhe = nullptr, *d_xh_av = nullptr, *d_xhe_av = nullptr, *d_xh_int = nullptr,
          *d_xhe_int = nullptr;
@@ -715,6 +733,9 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto &row : c->d_sed_tab)
+    for (double *p : row)
+      if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
                   c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT, c->d_rc_last, c->d_stat};
@@ -779,6 +800,7 @@ extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const doubl
     c->have_heat_tables = true;
   }
   HIPCHK(c, hipMemcpy(c->d_bands, &bd, sizeof bd, hipMemcpyHostToDevice));
+  c->bb_upper = bb_upper;
   c->have_tables = true;
   return 0;
 }
@@ -825,6 +847,42 @@ extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const do
   c->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
   c->normflux.assign(normflux, normflux + nsrc);
   c->s_star = s_star;
+  c->normflux_sed[0].clear();
+  c->normflux_sed[1].clear();
+  return 0;
+}
+
+extern "C" int c2r_set_sed_tables(c2r_ctx *c, int sed, const double *photo_thick, const double *photo_thin,
+                                  const double *heat_thick, const double *heat_thin, int lower, int upper) {
+  if (!c) return 1;
+  if (sed < 1 || sed > 2) return fail(c, "c2r_set_sed_tables: sed = %d, expected 1 (power law) or 2 (quasar)", sed);
+  if (!photo_thick || !photo_thin) return fail(c, "c2r_set_sed_tables: photo tables are required");
+  if (lower < 1 || upper > NFREQ || lower > upper)
+    return fail(c, "c2r_set_sed_tables: band range %d..%d not inside 1..%d", lower, upper, NFREQ);
+  HIPCHK(c, hipSetDevice(c->device));
+  const int k = sed - 1;
+  if (upload_table(c, photo_thick, NFREQ, &c->d_sed_tab[k][0])) return 1;
+  if (upload_table(c, photo_thin, NFREQ, &c->d_sed_tab[k][1])) return 1;
+  c->have_sed_heat[k] = false;
+  if (heat_thick && heat_thin) {
+    if (upload_table(c, heat_thick, NHEAT, &c->d_sed_tab[k][2])) return 1;
+    if (upload_table(c, heat_thin, NHEAT, &c->d_sed_tab[k][3])) return 1;
+    c->have_sed_heat[k] = true;
+  }
+  c->sed_lo[k] = lower - 1;
+  c->sed_hi[k] = upper;
+  c->have_sed[k] = true;
+  return 0;
+}
+
+extern "C" int c2r_set_sources_sed(c2r_ctx *c, int sed, const double *normflux, double s_star) {
+  if (!c) return 1;
+  if (sed < 1 || sed > 2) return fail(c, "c2r_set_sources_sed: sed = %d, expected 1 or 2", sed);
+  const int k = sed - 1;
+  if (!normflux) { c->normflux_sed[k].clear(); return 0; }
+  if (!c->have_sed[k]) return fail(c, "c2r_set_sources_sed: c2r_set_sed_tables(%d) has not been called", sed);
+  c->normflux_sed[k].assign(normflux, normflux + c->nsrc);
+  c->s_star_sed[k] = s_star;
   return 0;
 }
 
@@ -861,8 +919,32 @@ static int check_ready(c2r_ctx *c, const char *who) {
   if (!c->isothermal) {
     if (!c->have_heat_tables) return fail(c, "%s: non-isothermal run needs the heating tables", who);
     if (!c->have_cool) return fail(c, "%s: non-isothermal run needs c2r_set_cooling", who);
+    for (int k = 0; k < 2; k++)
+      if (c->have_sed[k] && !c->normflux_sed[k].empty() && !c->have_sed_heat[k])
+        return fail(c, "%s: non-isothermal run needs the heating tables of SED %d", who, k + 1);
   }
   return 0;
+}
+
+static SedSet sedset(c2r_ctx *c, bool *multi) {
+  SedSet ss;
+  const BandData *unused = nullptr;
+  (void)unused;
+  ss.photo_thick[0] = c->d_photo_thick; ss.photo_thin[0] = c->d_photo_thin;
+  ss.heat_thick[0] = c->d_heat_thick;   ss.heat_thin[0] = c->d_heat_thin;
+  ss.lo[0] = 0; ss.hi[0] = c->bb_upper;
+  *multi = false;
+  for (int k = 0; k < 2; k++) {
+    const bool on = c->have_sed[k] && !c->normflux_sed[k].empty();
+    ss.photo_thick[k + 1] = on ? c->d_sed_tab[k][0] : nullptr;
+    ss.photo_thin[k + 1] = on ? c->d_sed_tab[k][1] : nullptr;
+    ss.heat_thick[k + 1] = on ? c->d_sed_tab[k][2] : nullptr;
+    ss.heat_thin[k + 1] = on ? c->d_sed_tab[k][3] : nullptr;
+    ss.lo[k + 1] = on ? c->sed_lo[k] : 0;
+    ss.hi[k + 1] = on ? c->sed_hi[k] : 0;
+    *multi = *multi || on;
+  }
+  return ss;
 }
 
 static StepScalars scalars(c2r_ctx *c) {
@@ -953,6 +1035,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
   const Grid g = c->g;
   const size_t nc = g.ncell;
   const StepScalars sc = scalars(c);
+  bool multi = false;
+  const SedSet ss = sedset(c, &multi);
   const int mesh[3] = {g.n1, g.n2, g.n3};
   c->tm.sweep_ms = c->tm.rates_ms = 0.0;
   c->tm.sweep_launches = c->tm.rates_launches = 0;
@@ -986,7 +1070,10 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
         r.lastpos_l[d] = -std::min(MAX_SUBBOX, mesh[d] / 2);
         r.last_r[d] = r.last_l[d] = 0;
       }
-      r.total_flux = c->normflux[r.ns - 1] * c->s_star;
+      r.total_flux = c->normflux[r.ns - 1] * c->s_star; // evolve_source.F90:122-128
+      for (int k = 0; k < 2; k++)
+        if (multi && !c->normflux_sed[k].empty())
+          r.total_flux = r.total_flux + c->normflux_sed[k][r.ns - 1] * c->s_star_sed[k];
       r.loss = r.total_flux;
     }
     // coldensh_out = 0 for every new source (evolve_source.F90:94-95) serves two purposes in the
@@ -1005,6 +1092,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
       // while-test of evolve_source.F90:136-139 per source
       BatchArgs ba;
       ba.n = 0;
+      ba.multi = multi ? 1 : 0;
       int act_idx[MAXB];
       int s_lo = 1 << 30, s_hi = -1;
       for (int b = 0; b < nb; b++) {
@@ -1025,6 +1113,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
         S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
         for (int d = 0; d < 3; d++) { S.lo[d] = r.last_l[d]; S.hi[d] = r.last_r[d]; }
         S.nflux = c->normflux[r.ns - 1];
+        for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][r.ns - 1];
         S.slot = slot0 + b;
         S.pad = 0;
         act_idx[ba.n] = b;
@@ -1039,8 +1128,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
       for (int s = s_lo; s <= s_hi; s++) {
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         hipLaunchKernelGGL(k_sweep_shell, dim3(nblk, ba.n), dim3(BLOCK), 0, c->stream, g, ba, s, sc, c->d_ndens,
-                           c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_col, c->d_bands, c->d_photo_thick,
-                           c->d_photo_thin, c->d_loss_partial, c->blocks_total, c->block_base[s]);
+                           c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_col, c->d_bands, ss, c->d_loss_partial,
+                           c->blocks_total, c->block_base[s]);
         c->tm.sweep_launches++;
       }
       hipLaunchKernelGGL(k_loss_finish, dim3(ba.n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, c->blocks_total,
@@ -1070,26 +1159,29 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
     // rates of the whole batch, in source order, on the second stream
     BatchArgs ba;
     ba.n = nb;
+    ba.multi = multi ? 1 : 0;
     for (int b = 0; b < nb; b++) {
       SrcInfo &S = ba.s[b];
       const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
       S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
       for (int d = 0; d < 3; d++) { S.lo[d] = run[b].last_l[d]; S.hi[d] = run[b].last_r[d]; }
       S.nflux = c->normflux[run[b].ns - 1];
+      for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][run[b].ns - 1];
       S.slot = slot0 + b;
       S.pad = 0;
     }
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[set], 0));
     if (c->timing) HIPCHK(c, hipEventRecord(e_r0, c->stream2));
     const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
-    if (c->isothermal)
-      hipLaunchKernelGGL(k_rates<false>, dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
-                         c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
-                         c->d_heat_thin, c->d_rates);
-    else
-      hipLaunchKernelGGL(k_rates<true>, dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens, c->d_xh_av,
-                         c->d_xhe_av, c->d_col, c->d_bands, c->d_photo_thick, c->d_photo_thin, c->d_heat_thick,
-                         c->d_heat_thin, c->d_rates);
+#define C2R_LAUNCH_RATES(H, M)                                                                               \
+  hipLaunchKernelGGL((k_rates<H, M>), dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens,  \
+                     c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates)
+    if (c->isothermal) {
+      if (multi) C2R_LAUNCH_RATES(false, true); else C2R_LAUNCH_RATES(false, false);
+    } else {
+      if (multi) C2R_LAUNCH_RATES(true, true); else C2R_LAUNCH_RATES(true, false);
+    }
+#undef C2R_LAUNCH_RATES
     HIPCHK(c, hipGetLastError());
     c->tm.rates_launches++;
     if (c->timing) {

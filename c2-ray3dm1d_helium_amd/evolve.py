@@ -55,6 +55,20 @@ class RadiationTables:
     cool: np.ndarray | None = None
     cool_mintemp: float = 1.0
     cool_dtemp: float = 0.01
+    # -DPL / -DQUASARS builds: sed[1] (power law) / sed[2] (quasar-like) =
+    # dict(photo_thick, photo_thin, heat_thick, heat_thin, lower, upper)
+    sed: dict = field(default_factory=dict)
+
+    def add_sed_file(self, path):
+        """pl_* / qpl_* tables and band limits as dumped from a -DPL -DQUASARS reference build."""
+        with np.load(path) as z:
+            for idx, pre in ((1, "pl_"), (2, "qpl_")):
+                if pre + "photo_thick" in z.files:
+                    self.sed[idx] = dict(photo_thick=_f64(z[pre + "photo_thick"]), photo_thin=_f64(z[pre + "photo_thin"]),
+                                         heat_thick=_f64(z[pre + "heat_thick"]) if pre + "heat_thick" in z.files else None,
+                                         heat_thin=_f64(z[pre + "heat_thin"]) if pre + "heat_thin" in z.files else None,
+                                         lower=int(z[pre + "limits"][0]), upper=int(z[pre + "limits"][1]))
+        return self
 
     @classmethod
     def load(cls, path=DEFAULT_TABLES):
@@ -95,6 +109,10 @@ class SourceProps:
     srcpos: np.ndarray           # (NumSrc, 3) int32, 1-based mesh coordinates
     NormFlux: np.ndarray         # (NumSrc,) photons/s divided by S_star
     S_star: float = 1.0e48
+    NormFluxPL: np.ndarray | None = None    # -DPL builds
+    pl_S_star: float = 1.0e48
+    NormFluxQPL: np.ndarray | None = None   # -DQUASARS builds
+    qpl_S_star: float = 1.0e48
 
     @property
     def NumSrc(self):
@@ -148,6 +166,9 @@ class HipEngine:
                                           fv, int(t.bb_upper)))
         if t.cool is not None:
             self._chk(self.lib.c2r_set_cooling(self.h, _dp(t.cool), float(t.cool_mintemp), float(t.cool_dtemp)))
+        for idx, d in t.sed.items():
+            self._chk(self.lib.c2r_set_sed_tables(self.h, int(idx), _dp(d["photo_thick"]), _dp(d["photo_thin"]),
+                                                  _dp(d["heat_thick"]), _dp(d["heat_thin"]), d["lower"], d["upper"]))
 
     def set_step(self, mat: Material, grid: GridProps, cosmo: Cosmology):
         nd = _f64(mat.ndens).reshape(-1)
@@ -166,6 +187,11 @@ class HipEngine:
         self._chk(self.lib.c2r_set_sources(self.h, int(nf.size), pos.ctypes.data_as(C.POINTER(C.c_int)), _dp(nf),
                                            float(src.S_star)))
         self.nsrc = int(nf.size)
+        for idx, flux, star in ((1, src.NormFluxPL, src.pl_S_star), (2, src.NormFluxQPL, src.qpl_S_star)):
+            if flux is not None:
+                f = _f64(flux).reshape(-1)
+                assert f.size == nf.size
+                self._chk(self.lib.c2r_set_sources_sed(self.h, idx, _dp(f), float(star)))
 
     def upload_state(self, mat: Material):
         xh, xhe = _f64(mat.xh).reshape(-1), _f64(mat.xhe).reshape(-1)

@@ -80,6 +80,24 @@ module c2ray_hip
        real(c_double), value :: s_star
      end function c2r_set_sources
 
+     integer(c_int) function c2r_set_sed_tables(ctx, sed, photo_thick, photo_thin, heat_thick, heat_thin, &
+          lower, upper) bind(C, name="c2r_set_sed_tables")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: sed
+       real(c_double), intent(in) :: photo_thick(*), photo_thin(*)
+       type(c_ptr), value :: heat_thick, heat_thin
+       integer(c_int), value :: lower, upper
+     end function c2r_set_sed_tables
+
+     integer(c_int) function c2r_set_sources_sed(ctx, sed, normflux, s_star) bind(C, name="c2r_set_sources_sed")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: sed
+       real(c_double), intent(in) :: normflux(*)
+       real(c_double), value :: s_star
+     end function c2r_set_sources_sed
+
      integer(c_int) function c2r_upload_state(ctx, xh, xhe, temperature) bind(C, name="c2r_upload_state")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

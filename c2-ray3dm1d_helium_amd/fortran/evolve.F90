@@ -26,6 +26,20 @@ module evolve
   use radiation_sizes, only: f1heat_HI, f1heat_HeI, f1heat_HeII, f2heat_HI, f2heat_HeI, f2heat_HeII
   use radiation_tables, only: bb_photo_thick_table, bb_photo_thin_table
   use radiation_tables, only: bb_heat_thick_table, bb_heat_thin_table, bb_FreqBnd_UpperLimit
+#ifdef PL
+  use sourceprops, only: NormFluxPL
+  use radiation_sed_parameters, only: pl_S_star
+  use radiation_tables, only: pl_photo_thick_table, pl_photo_thin_table
+  use radiation_tables, only: pl_heat_thick_table, pl_heat_thin_table
+  use radiation_tables, only: pl_FreqBnd_LowerLimit, pl_FreqBnd_UpperLimit
+#endif
+#ifdef QUASARS
+  use sourceprops, only: NormFluxQPL
+  use radiation_sed_parameters, only: qpl_S_star
+  use radiation_tables, only: qpl_photo_thick_table, qpl_photo_thin_table
+  use radiation_tables, only: qpl_heat_thick_table, qpl_heat_thin_table
+  use radiation_tables, only: qpl_FreqBnd_LowerLimit, qpl_FreqBnd_UpperLimit
+#endif
   use cosmology, only: zred
   use cosmology_parameters, only: H0, Omega0
   use c2ray_parameters, only: convergence_fraction
@@ -100,6 +114,14 @@ contains
        call check (c2r_set_sources (hip_ctx, 0_c_int, (/ 0_c_int /), (/ 0.0_dp /), S_star), &
             "c2r_set_sources")
     endif
+#ifdef PL
+    if (NumSrc > 0) call check (c2r_set_sources_sed (hip_ctx, 1_c_int, NormFluxPL(1:NumSrc), pl_S_star), &
+         "c2r_set_sources_sed")
+#endif
+#ifdef QUASARS
+    if (NumSrc > 0) call check (c2r_set_sources_sed (hip_ctx, 2_c_int, NormFluxQPL(1:NumSrc), qpl_S_star), &
+         "c2r_set_sources_sed")
+#endif
     tptr = c_null_ptr
     if (.not.isothermal) tptr = c_loc_real4 (temperature_grid)
     call check (c2r_upload_state (hip_ctx, xh, xhe, tptr), "c2r_upload_state")
@@ -417,6 +439,27 @@ contains
     endif
     call check (c2r_set_tables (hip_ctx, bb_photo_thick_table, bb_photo_thin_table, ht, hn, &
          sigma_HI, sigma_HeI, sigma_HeII, fvec, int(bb_FreqBnd_UpperLimit,c_int)), "c2r_set_tables")
+
+#ifdef PL
+    ht = c_null_ptr
+    hn = c_null_ptr
+    if (allocated(pl_heat_thick_table)) then
+       ht = c_loc_2d (pl_heat_thick_table)
+       hn = c_loc_2d (pl_heat_thin_table)
+    endif
+    call check (c2r_set_sed_tables (hip_ctx, 1_c_int, pl_photo_thick_table, pl_photo_thin_table, ht, hn, &
+         int(pl_FreqBnd_LowerLimit,c_int), int(pl_FreqBnd_UpperLimit,c_int)), "c2r_set_sed_tables")
+#endif
+#ifdef QUASARS
+    ht = c_null_ptr
+    hn = c_null_ptr
+    if (allocated(qpl_heat_thick_table)) then
+       ht = c_loc_2d (qpl_heat_thick_table)
+       hn = c_loc_2d (qpl_heat_thin_table)
+    endif
+    call check (c2r_set_sed_tables (hip_ctx, 2_c_int, qpl_photo_thick_table, qpl_photo_thin_table, ht, hn, &
+         int(qpl_FreqBnd_LowerLimit,c_int), int(qpl_FreqBnd_UpperLimit,c_int)), "c2r_set_sed_tables")
+#endif
 
     if (.not.isothermal) then
        ! the cooling curves are private to the reference's radiative_cooling module, so the same

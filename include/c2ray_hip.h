@@ -63,6 +63,17 @@ int c2r_set_step(c2r_ctx *ctx, const double *ndens, const double dr[3], double v
  * radiation_sed_parameters:S_star (sourceprops_test.F90:38-40). */
 int c2r_set_sources(c2r_ctx *ctx, int nsrc, const int *srcpos, const double *normflux, double s_star);
 
+/* The -DPL / -DQUASARS builds of the reference give every source up to two more SEDs
+ * (radiation_photoionrates.f90:215-228, 256-271).  sed = 1: power law (pl_*), sed = 2: quasar-like (qpl_*).
+ *   c2r_set_sed_tables   pl_/qpl_photo_thick/thin_table, pl_/qpl_heat_thick/thin_table (heat may be NULL
+ *                        for isothermal-only use) and pl_/qpl_FreqBnd_LowerLimit..UpperLimit (1-based,
+ *                        inclusive; radiation_tables.f90:207-256)
+ *   c2r_set_sources_sed  NormFluxPL / NormFluxQPL(1:NumSrc) and pl_S_star / qpl_S_star; call after
+ *                        c2r_set_sources (which clears them); NULL switches the SED off again */
+int c2r_set_sed_tables(c2r_ctx *ctx, int sed, const double *photo_thick, const double *photo_thin,
+                       const double *heat_thick, const double *heat_thin, int lower, int upper);
+int c2r_set_sources_sed(c2r_ctx *ctx, int sed, const double *normflux, double s_star);
+
 /* material:xh, xhe, temperature_grid (temperature may be NULL when isothermal) */
 int c2r_upload_state(c2r_ctx *ctx, const double *xh, const double *xhe, const float *temperature);
 int c2r_download_state(c2r_ctx *ctx, double *xh, double *xhe, float *temperature);

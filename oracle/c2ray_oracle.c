@@ -350,22 +350,23 @@ static double read_table(const double *table, const tablepos *p, int b, int col)
 #define NB2 26
 #define NB3 20
 
-/* :331-464 (blackbody tables) */
-static void photo_lookuptable(const orc_tables *tb, const tablepos *pin, const tablepos *pout,
+/* :331-464; thick/thin = the SED's tables, bands lo..hi = its Minimum/Maximum_FreqBnd */
+static void photo_lookuptable(const double *thick, const double *thin, int lo, int hi, const tablepos *pin,
+                              const tablepos *pout,
                               const double *tau_in, const double *tau_out, double NFlux, double vol,
                               const double *sc_HI, const double *sc_HeI, const double *sc_HeII,
                               orc_photrates *r) {
   const double tau_photo_limit = F(1.0e-7);
   memset(r, 0, sizeof(*r));
-  for (int b = 1; b <= tb->bb_upper; b++) {
-    double phi_photo_in_all = NFlux * read_table(tb->photo_thick, pin, b, b);
+  for (int b = lo; b <= hi; b++) {
+    double phi_photo_in_all = NFlux * read_table(thick, pin, b, b);
     double phi_photo_out_all, phi_photo_all;
     r->photo_in = r->photo_in + phi_photo_in_all;
     if (fabs(tau_out[b - 1] - tau_in[b - 1]) > tau_photo_limit) {
-      phi_photo_out_all = NFlux * read_table(tb->photo_thick, pout, b, b);
+      phi_photo_out_all = NFlux * read_table(thick, pout, b, b);
       phi_photo_all = phi_photo_in_all - phi_photo_out_all;
     } else {
-      phi_photo_all = NFlux * (tau_out[b - 1] - tau_in[b - 1]) * read_table(tb->photo_thin, pin, b, b);
+      phi_photo_all = NFlux * (tau_out[b - 1] - tau_in[b - 1]) * read_table(thin, pin, b, b);
       phi_photo_out_all = phi_photo_in_all - phi_photo_all;
     }
     r->photo_out = r->photo_out + phi_photo_out_all;
@@ -383,7 +384,8 @@ static void photo_lookuptable(const orc_tables *tb, const tablepos *pin, const t
 }
 
 /* :470-779 */
-static void heat_lookuptable(const orc_tables *tb, const tablepos *pin, const tablepos *pout,
+static void heat_lookuptable(const orc_tables *tb, const double *thick, const double *thin, int lo, int hi,
+                             const tablepos *pin, const tablepos *pout,
                              const double *tau_in, const double *tau_out, const double *tau_cell_HI,
                              const double *tau_cell_HeI, const double *tau_cell_HeII, double NFlux,
                              double vol, double i_state, const double *sc_HI, const double *sc_HeI,
@@ -403,8 +405,7 @@ static void heat_lookuptable(const orc_tables *tb, const tablepos *pin, const ta
     double xeb = 1.0 - pow(i_state, bR2[i]);
     y2R[i] = CR2[i] * pow(i_state, aR2[i]) * xeb * xeb;
   }
-  const double *thick = tb->heat_thick, *thin = tb->heat_thin;
-  for (int b = 1; b <= tb->bb_upper; b++) {
+  for (int b = lo; b <= hi; b++) {
     double phi_heat_HI = 0.0, phi_heat_HeI = 0.0, phi_heat_HeII = 0.0;
     int optically_thick = fabs(tau_out[b - 1] - tau_in[b - 1]) > tau_heat_limit;
     if (b <= NB1) {
@@ -486,11 +487,13 @@ static void photrates_add(orc_photrates *a, const orc_photrates *b) { /* :827-85
   for (int i = 0; i < 21; i++) x[i] = x[i] + y[i];
 }
 
-/* :108-277 (blackbody SED; PL / QSO SEDs are cpp options not compiled into the test target) */
-void orc_photoion_rates(const orc_tables *tb, double colum_in_HI, double colum_out_HI,
-                        double colum_in_HeI, double colum_out_HeI, double colum_in_HeII,
-                        double colum_out_HeII, double vol, double normflux, double i_state,
-                        int isothermal, orc_photrates *out) {
+/* :108-277; normflux[0..2] = NormFlux, NormFluxPL, NormFluxQPL of the source (PL / QPL only in the
+ * -DPL -DQUASARS build: pass 0 and/or leave the tables NULL otherwise).  Order of the additions as in
+ * the reference: photo BB, PL, QPL, then heat BB, PL, QPL. */
+void orc_photoion_rates3(const orc_tables *tb, double colum_in_HI, double colum_out_HI,
+                         double colum_in_HeI, double colum_out_HeI, double colum_in_HeII,
+                         double colum_out_HeII, double vol, const double normflux[3], double i_state,
+                         int isothermal, orc_photrates *out) {
   double tau_in_all[ORC_NFREQ], tau_out_all[ORC_NFREQ];
   double tau_cell_HI[ORC_NFREQ], tau_cell_HeI[ORC_NFREQ], tau_cell_HeII[ORC_NFREQ];
   double sc_HI[ORC_NFREQ], sc_HeI[ORC_NFREQ], sc_HeII[ORC_NFREQ];
@@ -518,9 +521,17 @@ void orc_photoion_rates(const orc_tables *tb, double colum_in_HI, double colum_o
     sc_HeI[b] = colum_cell_HeI * tb->sigma_HeI[b] * forscaleing;
     sc_HeII[b] = colum_cell_HeII * tb->sigma_HeII[b] * forscaleing;
   }
-  if (normflux > 0.0) {
-    photo_lookuptable(tb, &pin, &pout, tau_in_all, tau_out_all, normflux, vol, sc_HI, sc_HeI, sc_HeII, &tmp);
-    photrates_add(&phi, &tmp);
+  const double *pthick[3] = {tb->photo_thick, tb->pl_photo_thick, tb->qpl_photo_thick};
+  const double *pthin[3] = {tb->photo_thin, tb->pl_photo_thin, tb->qpl_photo_thin};
+  const double *hthick[3] = {tb->heat_thick, tb->pl_heat_thick, tb->qpl_heat_thick};
+  const double *hthin[3] = {tb->heat_thin, tb->pl_heat_thin, tb->qpl_heat_thin};
+  const int lo[3] = {1, tb->pl_lower, tb->qpl_lower}, hi[3] = {tb->bb_upper, tb->pl_upper, tb->qpl_upper};
+  for (int sed = 0; sed < 3; sed++) {
+    if (pthick[sed] && normflux[sed] > 0.0) {
+      photo_lookuptable(pthick[sed], pthin[sed], lo[sed], hi[sed], &pin, &pout, tau_in_all, tau_out_all, normflux[sed],
+                        vol, sc_HI, sc_HeI, sc_HeII, &tmp);
+      photrates_add(&phi, &tmp);
+    }
   }
   if (!isothermal) {
     for (int b = 0; b < ORC_NFREQ; b++) {
@@ -528,13 +539,25 @@ void orc_photoion_rates(const orc_tables *tb, double colum_in_HI, double colum_o
       tau_cell_HeI[b] = colum_cell_HeI * tb->sigma_HeI[b];
       tau_cell_HeII[b] = colum_cell_HeII * tb->sigma_HeII[b];
     }
-    if (normflux > 0.0) {
-      heat_lookuptable(tb, &pin, &pout, tau_in_all, tau_out_all, tau_cell_HI, tau_cell_HeI, tau_cell_HeII,
-                       normflux, vol, i_state, sc_HI, sc_HeI, sc_HeII, &tmp);
-      photrates_add(&phi, &tmp);
+    for (int sed = 0; sed < 3; sed++) {
+      if (hthick[sed] && normflux[sed] > 0.0) {
+        heat_lookuptable(tb, hthick[sed], hthin[sed], lo[sed], hi[sed], &pin, &pout, tau_in_all, tau_out_all,
+                         tau_cell_HI, tau_cell_HeI, tau_cell_HeII, normflux[sed], vol, i_state, sc_HI, sc_HeI, sc_HeII,
+                         &tmp);
+        photrates_add(&phi, &tmp);
+      }
     }
   }
   *out = phi;
+}
+
+void orc_photoion_rates(const orc_tables *tb, double colum_in_HI, double colum_out_HI,
+                        double colum_in_HeI, double colum_out_HeI, double colum_in_HeII,
+                        double colum_out_HeII, double vol, double normflux, double i_state,
+                        int isothermal, orc_photrates *out) {
+  const double nf[3] = {normflux, 0.0, 0.0};
+  orc_photoion_rates3(tb, colum_in_HI, colum_out_HI, colum_in_HeI, colum_out_HeI, colum_in_HeII, colum_out_HeII, vol,
+                      nf, i_state, isothermal, out);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -675,9 +698,11 @@ static void evolve0D(const orc_tables *tb, const orc_step *st, orc_state *s, con
 
   orc_photrates phi;
   if (coldensh_in < max_coldensh) {
-    orc_photoion_rates(tb, coldensh_in, s->coldensh_out[q], coldenshe_in[0], s->coldenshe_out[q],
-                       coldenshe_in[1], s->coldenshe_out[q + ncell], vol_ph, st->normflux[ns - 1], h_av[1],
-                       st->isothermal, &phi);
+    const double nf[3] = {st->normflux[ns - 1], st->normflux_pl ? st->normflux_pl[ns - 1] : 0.0,
+                          st->normflux_qpl ? st->normflux_qpl[ns - 1] : 0.0};
+    orc_photoion_rates3(tb, coldensh_in, s->coldensh_out[q], coldenshe_in[0], s->coldenshe_out[q],
+                        coldenshe_in[1], s->coldenshe_out[q + ncell], vol_ph, nf, h_av[1],
+                        st->isothermal, &phi);
     phi.photo_cell_HI = phi.photo_cell_HI / (h_av[0] * ndens_p * (1.0 - abu_he));
     phi.photo_cell_HeI = phi.photo_cell_HeI / (he_av[0] * ndens_p * abu_he);
     phi.photo_cell_HeII = phi.photo_cell_HeII / (he_av[1] * ndens_p * abu_he);
@@ -723,7 +748,9 @@ int orc_do_source(const orc_tables *tb, const orc_step *st, orc_state *s, int ns
     lastpos_l[d] = src[d] - imin(MAX_SUBBOX, st->mesh[d] / 2);
   }
   int nbox = 0;
-  double total_source_flux = st->normflux[ns - 1] * st->s_star;
+  double total_source_flux = st->normflux[ns - 1] * st->s_star; /* evolve_source.F90:122-128 */
+  if (st->normflux_pl) total_source_flux = total_source_flux + st->normflux_pl[ns - 1] * st->pl_s_star;
+  if (st->normflux_qpl) total_source_flux = total_source_flux + st->normflux_qpl[ns - 1] * st->qpl_s_star;
   double photon_loss_src = total_source_flux;
   for (int d = 0; d < 3; d++) { cx.last_r[d] = src[d]; cx.last_l[d] = src[d]; }
   while (photon_loss_src > F(1e-10) * total_source_flux && cx.last_r[2] < lastpos_r[2] &&

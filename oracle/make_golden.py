@@ -95,6 +95,41 @@ def main():
             np.savez_compressed(GOLD / "funcvec.npz", **fv)
             tb = refrun.read_records(res / "tables.bin")
             np.savez_compressed(GOLD / "coolin_probe.npz", coolin_probe=tb["coolin_probe"])
+    # -DPL -DQUASARS build: three sources with black-body, power-law and quasar-like components;
+    # the hard photons keep ~60 cells flickering, so every evolve3D call runs into the 500-iteration
+    # cap (evolve.F90:177-181) -- 501 outer iterations to reproduce
+    subprocess.run([str(HERE / "ref_build.sh"), "16", "pl"], check=True)
+    srcs = [(8, 8, 8, 1e55, 3e54, 0.0), (2, 15, 4, 0.0, 2e54, 4e54), (16, 1, 9, 2e54, 0.0, 1e54)]
+    run = refrun.run_reference(16, srcs, isothermal=False, steps_per_slice=1, pl=True, name="golden_N16_pl_heat_3src")
+    conv = refrun.parse_log(run)
+    tin = refrun.read_records(run / "results" / "tap_0001_in.bin")
+    tout = refrun.read_records(run / "results" / "tap_0001_out.bin")
+    out = {"conv_flags_per_call": np.array([len(c) for c in conv], dtype=np.int32)}
+    for k, v in tin.items():
+        out["c1_in_" + k] = v
+    for k in ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av", "photon_loss_all",
+              "sum_nbox_all", "reccoef"]:
+        out["c1_out_" + k] = tout[k]
+    out["c1_conv_flags"] = np.array(conv[0], dtype=np.int32)
+    np.savez_compressed(GOLD / "tap_N16_pl_heat_3src.npz", **out)
+    tb = refrun.read_records(run / "results" / "tables.bin")
+    sed = {}
+    for pre in ("pl_", "qpl_"):
+        lo, hi = tb[pre + "limits"]
+        sed[pre + "limits"] = tb[pre + "limits"]
+        for kind, ncol in (("photo", 47), ("heat", 113)):
+            for tt in ("thick", "thin"):
+                a = tb[f"{pre}{kind}_{tt}"].reshape(ncol, 2001).copy()
+                # columns outside the SED's band range are never read: zero them so the file stays small
+                used = np.zeros(ncol, dtype=bool)
+                for b in range(lo, hi + 1):
+                    cols = [b] if kind == "photo" else ([1] if b == 1 else ([2 * b - 2, 2 * b - 1] if b <= 27 else
+                                                                            [3 * b - 30, 3 * b - 29, 3 * b - 28]))
+                    for c in cols:
+                        used[c - 1] = True
+                a[~used] = 0.0
+                sed[f"{pre}{kind}_{tt}"] = a.reshape(-1)
+    np.savez_compressed(GOLD / "rad_tables_pl_qpl.npz", **sed)
     for d in refrun.REFDIR.glob("golden_*"):
         shutil.rmtree(d)  # run directories are scratch
     for p in sorted(list(GOLD.glob("*.npz")) + list(PKGDATA.glob("*.npz"))):

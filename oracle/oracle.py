@@ -67,8 +67,11 @@ class CTables(C.Structure):
                 ("f2ion_HI", _dp), ("f2ion_HeI", _dp), ("f2ion_HeII", _dp),
                 ("f1heat_HI", _dp), ("f1heat_HeI", _dp), ("f1heat_HeII", _dp),
                 ("f2heat_HI", _dp), ("f2heat_HeI", _dp), ("f2heat_HeII", _dp),
-                ("bb_upper", C.c_int), ("cool", _dp), ("cool_mintemp", C.c_double),
-                ("cool_dtemp", C.c_double)]
+                ("bb_upper", C.c_int),
+                ("pl_photo_thick", _dp), ("pl_photo_thin", _dp), ("pl_heat_thick", _dp), ("pl_heat_thin", _dp),
+                ("qpl_photo_thick", _dp), ("qpl_photo_thin", _dp), ("qpl_heat_thick", _dp), ("qpl_heat_thin", _dp),
+                ("pl_lower", C.c_int), ("pl_upper", C.c_int), ("qpl_lower", C.c_int), ("qpl_upper", C.c_int),
+                ("cool", _dp), ("cool_mintemp", C.c_double), ("cool_dtemp", C.c_double)]
 
 
 class CStep(C.Structure):
@@ -76,6 +79,7 @@ class CStep(C.Structure):
                 ("zred", C.c_double), ("H0", C.c_double), ("Omega0", C.c_double),
                 ("isothermal", C.c_int), ("temper_val", C.c_double), ("clumping", C.c_float),
                 ("nsrc", C.c_int), ("srcpos", _ip), ("normflux", _dp), ("s_star", C.c_double),
+                ("normflux_pl", _dp), ("normflux_qpl", _dp), ("pl_s_star", C.c_double), ("qpl_s_star", C.c_double),
                 ("ndens", _dp), ("rc", RecCoef)]
 
 
@@ -112,6 +116,8 @@ def _p(a, t=_dp):
     return None if a is None else a.ctypes.data_as(t)
 
 
+SED_TABLE_KEYS = ["pl_photo_thick", "pl_photo_thin", "pl_heat_thick", "pl_heat_thin",
+                  "qpl_photo_thick", "qpl_photo_thin", "qpl_heat_thick", "qpl_heat_thin"]
 TABLE_KEYS = ["photo_thick", "photo_thin", "heat_thick", "heat_thin", "sigma_HI", "sigma_HeI", "sigma_HeII",
               "f1ion_HI", "f1ion_HeI", "f1ion_HeII", "f2ion_HI", "f2ion_HeI", "f2ion_HeII",
               "f1heat_HI", "f1heat_HeI", "f1heat_HeII", "f2heat_HI", "f2heat_HeI", "f2heat_HeII"]
@@ -121,7 +127,7 @@ class Tables:
     """Radiation + cooling tables as rad_ini / setup_cool leave them (a dict of numpy arrays)."""
 
     def __init__(self, d):
-        self.a = {k: np.ascontiguousarray(d[k], dtype=np.float64) for k in TABLE_KEYS if k in d}
+        self.a = {k: np.ascontiguousarray(d[k], dtype=np.float64) for k in TABLE_KEYS + SED_TABLE_KEYS if k in d}
         self.bb_upper = int(d["bb_upper"])
         self.cool = np.ascontiguousarray(d["cool"], dtype=np.float64) if "cool" in d else None
         self.cool_mintemp = float(d["cool_mintemp"]) if "cool_mintemp" in d else 1.0
@@ -130,6 +136,12 @@ class Tables:
         for k in TABLE_KEYS:
             setattr(c, k, _p(self.a.get(k)))
         c.bb_upper = self.bb_upper
+        for k in SED_TABLE_KEYS:
+            setattr(c, k, _p(self.a.get(k)))
+        if "pl_limits" in d:
+            c.pl_lower, c.pl_upper = int(d["pl_limits"][0]), int(d["pl_limits"][1])
+        if "qpl_limits" in d:
+            c.qpl_lower, c.qpl_upper = int(d["qpl_limits"][0]), int(d["qpl_limits"][1])
         c.cool = _p(self.cool)
         c.cool_mintemp = self.cool_mintemp
         c.cool_dtemp = self.cool_dtemp
@@ -145,7 +157,8 @@ class Step:
     """Host-side inputs of one evolve3D call (SURVEY.md section 8b 'Host data read')."""
 
     def __init__(self, mesh, dr, vol, zred, H0, Omega0, isothermal, temper_val, clumping, srcpos,
-                 normflux, s_star, ndens, reccoef):
+                 normflux, s_star, ndens, reccoef, normflux_pl=None, normflux_qpl=None, pl_s_star=1.0,
+                 qpl_s_star=1.0):
         self.srcpos = np.ascontiguousarray(srcpos, dtype=np.int32).reshape(-1)
         self.normflux = np.ascontiguousarray(normflux, dtype=np.float64).reshape(-1)
         self.ndens = np.ascontiguousarray(ndens, dtype=np.float64).reshape(-1)
@@ -161,6 +174,10 @@ class Step:
         c.srcpos = _p(self.srcpos, _ip)
         c.normflux = _p(self.normflux)
         c.s_star = float(s_star)
+        self.normflux_pl = None if normflux_pl is None else np.ascontiguousarray(normflux_pl, dtype=np.float64).reshape(-1)
+        self.normflux_qpl = None if normflux_qpl is None else np.ascontiguousarray(normflux_qpl, dtype=np.float64).reshape(-1)
+        c.normflux_pl, c.normflux_qpl = _p(self.normflux_pl), _p(self.normflux_qpl)
+        c.pl_s_star, c.qpl_s_star = float(pl_s_star), float(qpl_s_star)
         c.ndens = _p(self.ndens)
         c.rc = RecCoef.from_array(reccoef)
         self.c = c
@@ -171,7 +188,8 @@ class Step:
     def from_tap(cls, t):
         return cls(t["mesh"], t["dr"], t["vol"][0], t["zred"][0], t["H0"][0], t["Omega0"][0],
                    t["isothermal"][0], t["temper_val"][0], t["clumping"][0], t["srcpos"], t["NormFlux"],
-                   t["S_star"][0], t["ndens"], t["reccoef"])
+                   t["S_star"][0], t["ndens"], t["reccoef"], t.get("NormFluxPL"), t.get("NormFluxQPL"),
+                   t["pl_S_star"][0] if "pl_S_star" in t else 1.0, t["qpl_S_star"][0] if "qpl_S_star" in t else 1.0)
 
 
 class State:

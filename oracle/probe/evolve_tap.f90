@@ -16,6 +16,14 @@ subroutine evolve3d_tap(time, dt, restart) bind(C, name="__wrap__QMevolvePevolve
   use material, only: ndens, xh, xhe, temperature_grid, isothermal, temper_val, clumping
   use sourceprops, only: NumSrc, srcpos, NormFlux
   use radiation_sed_parameters, only: S_star
+#ifdef PL
+  use radiation_sed_parameters, only: pl_S_star
+  use sourceprops, only: NormFluxPL
+#endif
+#ifdef QUASARS
+  use radiation_sed_parameters, only: qpl_S_star
+  use sourceprops, only: NormFluxQPL
+#endif
   use cosmology, only: zred
   use cosmology_parameters, only: H0, Omega0
   use cgsconstants, only: arech0, brech0, areche0, breche0, oreche0, areche1, breche1, &
@@ -54,6 +62,14 @@ subroutine evolve3d_tap(time, dt, restart) bind(C, name="__wrap__QMevolvePevolve
   call put_i(u, "srcpos", srcpos, 3*NumSrc)
   call put_d(u, "NormFlux", NormFlux(1:NumSrc), NumSrc)
   call put_d(u, "S_star", (/S_star/), 1)
+#ifdef PL
+  call put_d(u, "NormFluxPL", NormFluxPL(1:NumSrc), NumSrc)
+  call put_d(u, "pl_S_star", (/pl_S_star/), 1)
+#endif
+#ifdef QUASARS
+  call put_d(u, "NormFluxQPL", NormFluxQPL(1:NumSrc), NumSrc)
+  call put_d(u, "qpl_S_star", (/qpl_S_star/), 1)
+#endif
   iso = 0
   if (isothermal) iso = 1
   call put_i(u, "isothermal", (/iso/), 1)
@@ -147,6 +163,14 @@ contains
     use radiation_tables, only: bb_photo_thick_table, bb_photo_thin_table, &
          bb_heat_thick_table, bb_heat_thin_table, bb_FreqBnd_UpperLimit, minlogtau, dlogtau
     use radiation_sed_parameters, only: T_eff, R_star, L_star
+#ifdef PL
+    use radiation_tables, only: pl_photo_thick_table, pl_photo_thin_table, pl_heat_thick_table, &
+         pl_heat_thin_table, pl_FreqBnd_UpperLimit, pl_FreqBnd_LowerLimit
+#endif
+#ifdef QUASARS
+    use radiation_tables, only: qpl_photo_thick_table, qpl_photo_thin_table, qpl_heat_thick_table, &
+         qpl_heat_thin_table, qpl_FreqBnd_UpperLimit, qpl_FreqBnd_LowerLimit
+#endif
     use radiation_photoionrates, only: photrates, photoion_rates
     use doric_module, only: doric, prepare_doric_factors
     use thermalevolution, only: thermal
@@ -207,6 +231,24 @@ contains
        call put_d(u, "heat_thick", bb_heat_thick_table, size(bb_heat_thick_table))
        call put_d(u, "heat_thin", bb_heat_thin_table, size(bb_heat_thin_table))
     endif
+#ifdef PL
+    call put_i(u, "pl_limits", (/pl_FreqBnd_LowerLimit, pl_FreqBnd_UpperLimit/), 2)
+    call put_d(u, "pl_photo_thick", pl_photo_thick_table, size(pl_photo_thick_table))
+    call put_d(u, "pl_photo_thin", pl_photo_thin_table, size(pl_photo_thin_table))
+    if (allocated(pl_heat_thick_table)) then
+       call put_d(u, "pl_heat_thick", pl_heat_thick_table, size(pl_heat_thick_table))
+       call put_d(u, "pl_heat_thin", pl_heat_thin_table, size(pl_heat_thin_table))
+    endif
+#endif
+#ifdef QUASARS
+    call put_i(u, "qpl_limits", (/qpl_FreqBnd_LowerLimit, qpl_FreqBnd_UpperLimit/), 2)
+    call put_d(u, "qpl_photo_thick", qpl_photo_thick_table, size(qpl_photo_thick_table))
+    call put_d(u, "qpl_photo_thin", qpl_photo_thin_table, size(qpl_photo_thin_table))
+    if (allocated(qpl_heat_thick_table)) then
+       call put_d(u, "qpl_heat_thick", qpl_heat_thick_table, size(qpl_heat_thick_table))
+       call put_d(u, "qpl_heat_thin", qpl_heat_thin_table, size(qpl_heat_thin_table))
+    endif
+#endif
     if (.not. isothermal) then
        ! cooling curve sampled through the public interface: coolin with unit densities
        ! and one species switched on recovers each table value*(abundance) exactly

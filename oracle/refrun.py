@@ -43,16 +43,17 @@ def read_records(path) -> dict:
     return out
 
 
-def ref_binary(mesh: int, which: str = "tap", omp: bool = False) -> Path:
-    tag = f"N{mesh}" + ("_omp" if omp else "")
+def ref_binary(mesh: int, which: str = "tap", omp: bool = False, pl: bool = False) -> Path:
+    tag = f"N{mesh}" + ("_omp" if omp else "") + ("_pl" if pl else "")
     return REFDIR / tag / f"C2Ray_3D_{which}"
 
 
 def run_reference(mesh: int, sources, *, T0=1e4, isothermal=True, steps_per_slice=1,
                   outputs_per_slice=1, which="tap", omp=False, name=None, threads=1,
-                  timeout=3600, keep=True):
-    """Run the reference; returns the run directory (results in <run>/results)."""
-    exe = ref_binary(mesh, which, omp)
+                  timeout=3600, keep=True, pl=False):
+    """Run the reference; returns the run directory (results in <run>/results).
+    sources: (i, j, k, S_BB) or, for the -DPL -DQUASARS build (pl=True), (i, j, k, S_BB, S_PL, S_QPL)."""
+    exe = ref_binary(mesh, which, omp, pl)
     if not exe.exists():
         raise FileNotFoundError(f"{exe} missing: run oracle/ref_build.sh {mesh}")
     name = name or f"run_N{mesh}_{'iso' if isothermal else 'heat'}_{len(sources)}src"
@@ -62,8 +63,9 @@ def run_reference(mesh: int, sources, *, T0=1e4, isothermal=True, steps_per_slic
     (run / "results").mkdir(parents=True)
     with open(run / "test_sources.dat", "w") as f:
         f.write(f"{len(sources)}\n")
-        for (i, j, k, s) in sources:
-            f.write(f"{i} {j} {k} {s:.6e}\n")
+        for src in sources:
+            i, j, k = src[:3]
+            f.write(f"{i} {j} {k} " + " ".join(f"{x:.6e}" for x in src[3:]) + "\n")
     with open(run / "input", "w") as f:
         f.write("0 1 1 0 0\n")
         f.write(f"{T0:g}\n")

@@ -68,6 +68,45 @@ void hh_photoion(const double *cin6, double vol, double nflux, double i_state, i
   out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
 }
 
+// the three-SED variant: tables of SED 1 (pl) and 2 (qpl) in the same layout as the BB ones
+namespace {
+std::vector<double> S_pt[2], S_pn[2], S_ht[2], S_hn[2];
+int S_lo[2] = {0, 0}, S_hi[2] = {0, 0};
+}
+void hh_set_sed(int sed, const double *pthick, const double *pthin, const double *hthick, const double *hthin, int lower,
+                int upper) {
+  const int k = sed - 1;
+  pitch(pthick, NFREQ, S_pt[k]);
+  pitch(pthin, NFREQ, S_pn[k]);
+  pitch(hthick, NHEAT, S_ht[k]);
+  pitch(hthin, NHEAT, S_hn[k]);
+  S_lo[k] = lower - 1;
+  S_hi[k] = upper;
+}
+static SedSet make_sedset() {
+  SedSet ss;
+  ss.photo_thick[0] = T.pthick.data(); ss.photo_thin[0] = T.pthin.data();
+  ss.heat_thick[0] = T.hthick.data(); ss.heat_thin[0] = T.hthin.data();
+  ss.lo[0] = 0; ss.hi[0] = T.bd.bb_upper;
+  for (int k = 0; k < 2; k++) {
+    ss.photo_thick[k + 1] = S_pt[k].data(); ss.photo_thin[k + 1] = S_pn[k].data();
+    ss.heat_thick[k + 1] = S_ht[k].data(); ss.heat_thin[k + 1] = S_hn[k].data();
+    ss.lo[k + 1] = S_lo[k]; ss.hi[k + 1] = S_hi[k];
+  }
+  return ss;
+}
+void hh_photoion_multi(const double *cin6, double vol, const double *nflux3, double i_state, int heat, double *out5) {
+  PhotoOut o;
+  const SedSet ss = make_sedset();
+  if (heat) photoion_rates_multi<true>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, i_state, o);
+  else photoion_rates_multi<false>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, i_state, o);
+  out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
+}
+double hh_photo_out_multi(const double *cin6, const double *nflux3) {
+  const SedSet ss = make_sedset();
+  return photo_out_multi(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], nflux3);
+}
+
 double hh_photo_out_only(const double *cin6, double nflux) {
   return photo_out_only(T.bd, T.pthick.data(), T.pthin.data(), cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5],
                         nflux);

@@ -100,3 +100,30 @@ def test_cinterp_equals_oracle_everywhere(hh, orc, gold):
                     orc.lib().orc_cinterp(mesh.ctypes.data_as(ip), _p(cH), _p(cHe), pos.ctypes.data_as(ip),
                                           src.ctypes.data_as(ip), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
                     assert (out[0], out[1], out[2], out[3]) == (a.value, b.value, c.value, d.value), (di, dj, dk)
+
+
+def test_multi_sed_photoion_equals_oracle(hh, orc, pkg, gold):
+    """photoion_rates_multi / photo_out_multi (three SEDs: black body, power law, quasar-like) against the
+    oracle's orc_photoion_rates3 on the reference's own tables, every on/off combination of the SEDs."""
+    from test_oracle_golden import _pl_tables
+    T = _pl_tables(orc, pkg, gold)
+    z = gold("rad_tables_pl_qpl.npz")
+    for idx, pre in ((1, "pl_"), (2, "qpl_")):
+        a = [np.ascontiguousarray(z[pre + k]) for k in ("photo_thick", "photo_thin", "heat_thick", "heat_thin")]
+        hh.hh_set_sed(idx, *[_p(x) for x in a], C.c_int(int(z[pre + "limits"][0])), C.c_int(int(z[pre + "limits"][1])))
+    vec = gold("funcvec.npz")["photoion_heat"].reshape(-1, 30)[:120]
+    rng = np.random.default_rng(5)
+    out = np.empty(5)
+    ref = orc.PhotRates()
+    for n, row in enumerate(vec):
+        nf = np.array([row[8], 10.0 ** rng.uniform(5, 7), 10.0 ** rng.uniform(5, 7)])
+        nf *= np.array([(n >> 0) & 1, (n >> 1) & 1, (n >> 2) & 1], dtype=float)
+        cin = np.ascontiguousarray(row[:6])
+        for heat in (0, 1):
+            hh.hh_photoion_multi(_p(cin), C.c_double(row[6]), _p(nf), C.c_double(row[7]), C.c_int(heat), _p(out))
+            orc.lib().orc_photoion_rates3(C.byref(T.c), *[C.c_double(x) for x in cin], C.c_double(row[6]),
+                                          (C.c_double * 3)(*nf), C.c_double(row[7]), C.c_int(1 - heat), C.byref(ref))
+            r = ref.as_array()
+            assert np.array_equal(out, r[[0, 1, 2, 18, 20]]), (n, heat)
+        hh.hh_photo_out_multi.restype = C.c_double
+        assert hh.hh_photo_out_multi(_p(cin), _p(nf)) == r[20]

@@ -76,3 +76,27 @@ def test_n22_far_layer_never_traced(orc, otables, gold):
     far = (src - 1 - 11) % 22
     assert np.all(col[far[0], :, :] == 0.0) and np.all(col[:, far[1], :] == 0.0) and np.all(col[:, :, far[2]] == 0.0)
     assert np.count_nonzero(col) == 21 ** 3
+
+
+def _pl_tables(orc, pkg, gold):
+    with np.load(pkg.evolve.DEFAULT_TABLES) as t:
+        d = {k: t[k] for k in t.files}
+    z = gold("rad_tables_pl_qpl.npz")
+    d.update({k: z[k] for k in z.files})
+    return orc.Tables(d)
+
+
+def test_evolve3d_with_power_law_and_quasar_seds(orc, pkg, gold):
+    """-DPL -DQUASARS build of the reference: three SEDs per source.  The hard photons keep a few dozen
+    cells flickering, so the call runs into the 500-iteration cap: 501 outer iterations, all
+    non-converged counts and every output array bit-identical."""
+    T = _pl_tables(orc, pkg, gold)
+    i, o = tap_case(gold("tap_N16_pl_heat_3src.npz"), 1)
+    st = orc.Step.from_tap(i)
+    s = orc.State(st, i["xh"], i["xhe"], i["temperature"])
+    nit = orc.evolve3d(T, st, s, i["dt"][0])
+    assert nit == 501 == len(o["conv_flags"])
+    assert s.conv_flags == list(o["conv_flags"])
+    for k, attr in {"xh": "xh", "xhe": "xhe", "temperature": "temperature", "phih_grid": "phih", "phihe_grid": "phihe",
+                    "phiheat": "phiheat", "xh_av": "xh_av", "xhe_av": "xhe_av", "photon_loss_all": "photon_loss"}.items():
+        assert np.array_equal(getattr(s, attr), o[k]), k
