@@ -40,6 +40,8 @@ SYMBOLS = {
     "c2r_set_sources": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double]),
     "c2r_set_sed_tables": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int]),
     "c2r_set_sources_sed": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double]),
+    "c2r_set_lls": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _fp]),
+    "c2r_set_clumping_grid": (C.c_int, [C.c_void_p, _fp]),
     "c2r_upload_state": (C.c_int, [C.c_void_p, _dp, _dp, _fp]),
     "c2r_download_state": (C.c_int, [C.c_void_p, _dp, _dp, _fp]),
     "c2r_evolve3d": (C.c_int, [C.c_void_p, C.c_double, _ip, _ip, C.c_int]),

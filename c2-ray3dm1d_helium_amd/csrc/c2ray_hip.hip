@@ -58,6 +58,8 @@ struct StepScalars {
   double temper_val;
   RecCoef rc;
   CoolData cd;
+  int use_lls;          // c2ray_parameters: use_LLS
+  double coldensh_lls;  // material: coldensh_LLS (type_of_LLS = 1)
 };
 
 __device__ __forceinline__ int wrap0(int x, int n) { // 0-based periodic index of x in [-n, 2n)
@@ -172,7 +174,7 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
               const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
               const double *__restrict__ stateT, double *__restrict__ col,
               const BandData *__restrict__ bd, SedSet ss, double *__restrict__ loss_partial, int blocks_total,
-              int block_base) {
+              int block_base, const float *__restrict__ lls_grid) {
   __shared__ double sh[BLOCK / 64];
   const SrcInfo &S = ba.s[blockIdx.y];
   const long long cnt = shell_count(shell);
@@ -223,6 +225,13 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
         const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
         const double dist2 = xs * xs + ys * ys + zs * zs;
         vol_ph = 4.0 * pi * dist2 * path;
+        if (sc.use_lls) {
+          // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180); the per-cell
+          // grid is LLS_point of type_of_LLS = 2 (REAL(4), mat_ini_cubep3m.F90:859-870)
+          const double coldensh_LLS =
+              lls_grid ? (double)lls_grid[cell_index(g, S.i0, S.j0, S.k0, di, dj, dk)] : sc.coldensh_lls;
+          cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
+        }
       }
       const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
       const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
@@ -366,11 +375,14 @@ __global__ void __launch_bounds__(BLOCK)
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
-            const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last) {
+            const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
+            const float *__restrict__ clumping_grid) {
   const size_t nc = g.ncell;
   const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   int notconv = 0;
   if (q < nc) {
+    // clumping_point for type_of_clumping = 5 (evolve_point.F90:483-484; REAL(4) grid)
+    const double clumping = clumping_grid ? (double)clumping_grid[q] : sc.clumping;
     IonStates ion;
     ion.h[0] = dmax(epsilon, xh_int[q]);       ion.h[1] = dmax(epsilon, xh_int[q + nc]);
     ion.h_old[0] = dmax(epsilon, xh[q]);       ion.h_old[1] = dmax(epsilon, xh[q + nc]);
@@ -411,14 +423,14 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
       double yfrac, zfrac, y2afrac, y2bfrac;
       prepare_doric_factors(coldens(path, ion.h[0], ndens_p, (1.0 - abu_he)), coldens(path, ion.he[0], ndens_p, abu_he),
                             coldens(path, ion.he[1], ndens_p, abu_he), yfrac, zfrac, y2afrac, y2bfrac);
-      doric(dt, de, ion, phi_HI, phi_HeI, phi_HeII, yfrac, zfrac, y2afrac, y2bfrac, rc, sc.clumping);
+      doric(dt, de, ion, phi_HI, phi_HeI, phi_HeII, yfrac, zfrac, y2afrac, y2bfrac, rc, clumping);
       de = electrondens(ndens_p, ion.h_av, ion.he_av);
       prepare_doric_factors(coldens(path, ion.h[0], ndens_p, (1.0 - abu_he)), coldens(path, ion.he[0], ndens_p, abu_he),
                             coldens(path, ion.he[1], ndens_p, abu_he), yfrac, zfrac, y2afrac, y2bfrac);
       const double ionh0old = ion.h[0], ionh1old = ion.h[1];
       const double ionhe0old = ion.he[0], ionhe1old = ion.he[1], ionhe2old = ion.he[2];
       const double oldhav = ion.h_av[0], oldhe0av = ion.he_av[0], oldhe1av = ion.he_av[1];
-      doric(dt, de, ion, phi_HI, phi_HeI, phi_HeII, yfrac, zfrac, y2afrac, y2bfrac, rc, sc.clumping);
+      doric(dt, de, ion, phi_HI, phi_HeI, phi_HeII, yfrac, zfrac, y2afrac, y2bfrac, rc, clumping);
       ion.h[0] = (ion.h[0] + ionh0old) / 2.0;
       ion.h[1] = (ion.h[1] + ionh1old) / 2.0;
       ion.he[0] = (ion.he[0] + ionhe0old) / 2.0;
@@ -512,10 +524,12 @@ k_state_sums(size_t nc, const double *__restrict__ ndens, const double *__restri
 }
 
 __global__ void __launch_bounds__(BLOCK)
-k_total_rates(size_t nc, RecCoef rc, double clumping, const double *__restrict__ ndens,
-              const double *__restrict__ xh, const double *__restrict__ xhe, double *__restrict__ partial) {
+k_total_rates(size_t nc, RecCoef rc, double clumping_scalar, const float *__restrict__ clumping_grid,
+              const double *__restrict__ ndens, const double *__restrict__ xh, const double *__restrict__ xhe,
+              double *__restrict__ partial) {
   double v[3] = {0.0, 0.0, 0.0};
   for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nc; q += (size_t)gridDim.x * BLOCK) {
+    const double clumping = clumping_grid ? (double)clumping_grid[q] : clumping_scalar; // photonstatistics.f90:175-177
     const double nd = ndens[q];
     const double yh[2] = {xh[q], xh[q + nc]};
     const double yhe[3] = {xhe[q], xhe[q + nc], xhe[q + 2 * nc]};
@@ -568,6 +582,8 @@ struct c2r_ctx {
   double zred = 0, H0 = 0, Omega0 = 0;
   int isothermal = 1;
   bool have_step = false;
+  float *d_lls = nullptr, *d_clump = nullptr; // LLS_grid (type_of_LLS = 2), clumping_grid (type_of_clumping = 5)
+  bool lls_on_grid = false, clumping_on_grid = false;
 
   int nsrc = 0;
   std::vector<int> srcpos;
@@ -738,7 +754,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT, c->d_rc_last, c->d_stat};
+                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
@@ -883,6 +899,34 @@ extern "C" int c2r_set_sources_sed(c2r_ctx *c, int sed, const double *normflux, 
   if (!c->have_sed[k]) return fail(c, "c2r_set_sources_sed: c2r_set_sed_tables(%d) has not been called", sed);
   c->normflux_sed[k].assign(normflux, normflux + c->nsrc);
   c->s_star_sed[k] = s_star;
+  return 0;
+}
+
+extern "C" int c2r_set_lls(c2r_ctx *c, int use_lls, double coldensh_lls, const float *lls_grid) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->sc.use_lls = use_lls ? 1 : 0;
+  c->sc.coldensh_lls = coldensh_lls;
+  c->lls_on_grid = false;
+  if (use_lls && lls_grid) {
+    if (!c->d_lls) HIPCHK(c, hipMalloc(&c->d_lls, sizeof(float) * c->g.ncell));
+    HIPCHK(c, hipMemcpyAsync(c->d_lls, lls_grid, sizeof(float) * c->g.ncell, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->lls_on_grid = true;
+  }
+  return 0;
+}
+
+extern "C" int c2r_set_clumping_grid(c2r_ctx *c, const float *clumping_grid) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->clumping_on_grid = false;
+  if (clumping_grid) {
+    if (!c->d_clump) HIPCHK(c, hipMalloc(&c->d_clump, sizeof(float) * c->g.ncell));
+    HIPCHK(c, hipMemcpyAsync(c->d_clump, clumping_grid, sizeof(float) * c->g.ncell, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->clumping_on_grid = true;
+  }
   return 0;
 }
 
@@ -1129,7 +1173,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         hipLaunchKernelGGL(k_sweep_shell, dim3(nblk, ba.n), dim3(BLOCK), 0, c->stream, g, ba, s, sc, c->d_ndens,
                            c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_col, c->d_bands, ss, c->d_loss_partial,
-                           c->blocks_total, c->block_base[s]);
+                           c->blocks_total, c->block_base[s], c->lls_on_grid ? c->d_lls : nullptr);
         c->tm.sweep_launches++;
       }
       hipLaunchKernelGGL(k_loss_finish, dim3(ba.n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, c->blocks_total,
@@ -1245,11 +1289,11 @@ extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
   if (c->isothermal)
     hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
-                       c->d_rc_last);
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr);
   else
     hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
-                       c->d_rc_last);
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr);
   HIPCHK(c, hipGetLastError());
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1420,7 +1464,7 @@ extern "C" int c2r_total_rates(c2r_ctx *c, double dt, const double reccoef[12], 
   RecCoef rc;
   std::memcpy(&rc, reccoef, sizeof rc);
   hipLaunchKernelGGL(k_total_rates, dim3(STAT_BLOCKS), dim3(BLOCK), 0, c->stream, c->g.ncell, rc, c->sc.clumping,
-                     c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stat);
+                     c->clumping_on_grid ? c->d_clump : nullptr, c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stat);
   hipLaunchKernelGGL(k_stat_finish<3>, dim3(1), dim3(BLOCK), 0, c->stream, c->d_stat, STAT_BLOCKS, c->d_stat + STAT_BLOCKS * 5);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_stat, c->d_stat + STAT_BLOCKS * 5, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));

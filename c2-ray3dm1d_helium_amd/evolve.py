@@ -93,6 +93,12 @@ class Material:
     temper_val: float = 1.0e4
     clumping: float = 1.0
     reccoef: np.ndarray = field(default_factory=lambda: np.zeros(12))  # cgsconstants.f90:106-133
+    # type_of_clumping = 5: REAL(4) clumping_grid(mesh) read per cell (mat_ini_cubep3m.F90:635-646)
+    clumping_grid: np.ndarray | None = None
+    # use_LLS (c2ray_parameters.f90:72-78): coldensh_LLS of type 1, or the REAL(4) LLS_grid of type 2
+    use_LLS: bool = False
+    coldensh_LLS: float = 0.0
+    LLS_grid: np.ndarray | None = None
 
 
 @dataclass
@@ -179,6 +185,14 @@ class HipEngine:
         self._chk(self.lib.c2r_set_step(self.h, _dp(nd), dr, float(grid.vol), float(mat.clumping), float(cosmo.zred),
                                         float(cosmo.H0), float(cosmo.Omega0), int(bool(mat.isothermal)),
                                         float(mat.temper_val), _dp(rc)))
+        lls = None if mat.LLS_grid is None else np.ascontiguousarray(mat.LLS_grid, dtype=np.float32).reshape(-1)
+        cg = None if mat.clumping_grid is None else np.ascontiguousarray(mat.clumping_grid, dtype=np.float32).reshape(-1)
+        assert lls is None or lls.size == self.ncell
+        assert cg is None or cg.size == self.ncell
+        fp = C.POINTER(C.c_float)
+        self._chk(self.lib.c2r_set_lls(self.h, int(bool(mat.use_LLS)), float(mat.coldensh_LLS),
+                                       None if lls is None else lls.ctypes.data_as(fp)))
+        self._chk(self.lib.c2r_set_clumping_grid(self.h, None if cg is None else cg.ctypes.data_as(fp)))
 
     def set_sources(self, src: SourceProps):
         pos = np.ascontiguousarray(src.srcpos, dtype=np.int32).reshape(-1)

@@ -98,6 +98,20 @@ module c2ray_hip
        real(c_double), value :: s_star
      end function c2r_set_sources_sed
 
+     integer(c_int) function c2r_set_lls(ctx, use_lls, coldensh_lls, lls_grid) bind(C, name="c2r_set_lls")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: use_lls
+       real(c_double), value :: coldensh_lls
+       type(c_ptr), value :: lls_grid            ! real(c_float) (mesh) or c_null_ptr
+     end function c2r_set_lls
+
+     integer(c_int) function c2r_set_clumping_grid(ctx, clumping_grid) bind(C, name="c2r_set_clumping_grid")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: clumping_grid       ! real(c_float) (mesh) or c_null_ptr
+     end function c2r_set_clumping_grid
+
      integer(c_int) function c2r_upload_state(ctx, xh, xhe, temperature) bind(C, name="c2r_upload_state")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

@@ -43,6 +43,8 @@ module evolve
   use cosmology, only: zred
   use cosmology_parameters, only: H0, Omega0
   use c2ray_parameters, only: convergence_fraction
+  use c2ray_parameters, only: use_LLS, type_of_LLS, type_of_clumping
+  use material, only: coldensh_LLS, LLS_point, clumping_point
   use cgsconstants, only: arech0, brech0, areche0, breche0, oreche0, areche1, breche1, treche1
   use cgsconstants, only: colli_HI, colli_HeI, colli_HeII, v
   use photonstatistics, only: photon_loss, LLS_loss
@@ -107,6 +109,7 @@ contains
          colli_HI, colli_HeI, colli_HeII, v /)
     call check (c2r_set_step (hip_ctx, ndens, dr, vol, real(clumping,c_float), zred, H0, Omega0, &
          iso, temper_val, reccoef), "c2r_set_step")
+    call pass_subgrid_fields ()
     if (NumSrc > 0) then
        call check (c2r_set_sources (hip_ctx, int(NumSrc,c_int), srcpos, NormFlux(1:NumSrc), S_star), &
             "c2r_set_sources")
@@ -200,6 +203,50 @@ contains
   ! ===========================================================================
 
   !> Ray trace the whole grid for all sources of this rank and sum over the ranks
+  subroutine pass_subgrid_fields ()
+
+    ! use_LLS (evolve_point.F90:177-180) and type_of_clumping == 5 (evolve_point.F90:483-484).
+    ! The grids behind LLS_point / clumping_point are private to module material, so they are read
+    ! through those public accessors, which is what the reference's evolve0D / do_chemistry do per cell.
+    real(c_float),dimension(:,:,:),allocatable,target,save :: field
+    real :: clumping_saved
+    integer :: i,j,k
+
+    if (use_LLS) then
+       if (type_of_LLS == 2) then
+          if (.not.allocated(field)) allocate(field(mesh(1),mesh(2),mesh(3)))
+          do k=1,mesh(3)
+             do j=1,mesh(2)
+                do i=1,mesh(1)
+                   call LLS_point (i,j,k)
+                   field(i,j,k)=real(coldensh_LLS,c_float)
+                enddo
+             enddo
+          enddo
+          call check (c2r_set_lls (hip_ctx, 1_c_int, coldensh_LLS, c_loc(field)), "c2r_set_lls")
+       else
+          call check (c2r_set_lls (hip_ctx, 1_c_int, coldensh_LLS, c_null_ptr), "c2r_set_lls")
+       endif
+    endif
+    if (type_of_clumping == 5) then
+       if (.not.allocated(field)) allocate(field(mesh(1),mesh(2),mesh(3)))
+       clumping_saved=clumping
+       do k=1,mesh(3)
+          do j=1,mesh(2)
+             do i=1,mesh(1)
+                call clumping_point (i,j,k)
+                field(i,j,k)=real(clumping,c_float)
+             enddo
+          enddo
+       enddo
+       clumping=clumping_saved
+       call check (c2r_set_clumping_grid (hip_ctx, c_loc(field)), "c2r_set_clumping_grid")
+    endif
+
+  end subroutine pass_subgrid_fields
+
+  !----------------------------------------------------------------------------
+
   subroutine pass_all_sources ()
 
     integer(c_int) :: nbox

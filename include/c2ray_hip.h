@@ -59,6 +59,20 @@ int c2r_set_step(c2r_ctx *ctx, const double *ndens, const double dr[3], double v
                  double zred, double H0, double Omega0, int isothermal, double temper_val,
                  const double reccoef[12]);
 
+/* Lyman-limit systems (c2ray_parameters.f90:72-78 use_LLS, type_of_LLS): a fog of unresolved absorbers added
+ * to the incoming HI column of every cell but the source's, coldensh_in += coldensh_LLS*path/dr(1)
+ * (evolve_point.F90:177-180).  use_lls = 0 switches it off (the reference's default); lls_grid == NULL is
+ * type_of_LLS = 1 with material:coldensh_LLS as set by set_LLS each step (mat_ini_test.F90:640-662);
+ * lls_grid != NULL is type_of_LLS = 2: material's REAL(4) LLS_grid(mesh) read per cell by LLS_point
+ * (mat_ini_cubep3m.F90:859-870).  Stays in force until the next call.  LLS_loss stays 0 as in the
+ * reference (it multiplies photo_in_HI, which photoion_rates never sets). */
+int c2r_set_lls(c2r_ctx *ctx, int use_lls, double coldensh_lls, const float *lls_grid);
+
+/* Position-dependent clumping, type_of_clumping = 5: material's REAL(4) clumping_grid(mesh), read per cell
+ * by clumping_point in do_chemistry (evolve_point.F90:483-484) and in total_rates
+ * (photonstatistics.f90:175-177).  NULL returns to the scalar material:clumping of c2r_set_step. */
+int c2r_set_clumping_grid(c2r_ctx *ctx, const float *clumping_grid);
+
 /* sourceprops: NumSrc, srcpos(3,NumSrc) (1-based mesh coordinates), NormFlux(1:NumSrc), and
  * radiation_sed_parameters:S_star (sourceprops_test.F90:38-40). */
 int c2r_set_sources(c2r_ctx *ctx, int nsrc, const int *srcpos, const double *normflux, double s_star);

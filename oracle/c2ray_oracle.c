@@ -691,6 +691,10 @@ static void evolve0D(const orc_tables *tb, const orc_step *st, orc_state *s, con
     double zs = st->dr[2] * (double)(float)(rtpos[2] - src[2]);
     double dist2 = xs * xs + ys * ys + zs * zs;
     vol_ph = 4.0 * pi * dist2 * path;
+    if (st->use_lls) { /* :177-180 */
+      const double coldensh_LLS = st->lls_grid ? (double)st->lls_grid[q] : st->coldensh_lls;
+      coldensh_in = coldensh_in + coldensh_LLS * path / st->dr[0];
+    }
   }
   s->coldensh_out[q] = coldensh_in + coldens(path, h_av[0], ndens_p, (1.0 - abu_he));
   s->coldenshe_out[q] = coldenshe_in[0] + coldens(path, he_av[0], ndens_p, abu_he);
@@ -805,6 +809,8 @@ static void do_chemistry(const orc_tables *tb, const orc_step *st, orc_state *s,
   (void)temper_inter;
   temper0 = temper1;
   const double path = 1.0;
+  /* :483-484 clumping_point when type_of_clumping == 5 */
+  const float clumping = st->clumping_grid ? st->clumping_grid[q] : st->clumping;
   int nit = 0;
   for (;;) {
     nit++;
@@ -821,7 +827,7 @@ static void do_chemistry(const orc_tables *tb, const orc_step *st, orc_state *s,
     coldenshe_cell[1] = coldens(path, ion->he[1], ndens_p, abu_he);
     double yfrac, zfrac, y2afrac, y2bfrac;
     orc_prepare_doric_factors(coldensh_cell, coldenshe_cell, &yfrac, &zfrac, &y2afrac, &y2bfrac);
-    orc_doric(dt, de, ndens_p, ion, phi, yfrac, zfrac, y2afrac, y2bfrac, &rc, st->clumping);
+    orc_doric(dt, de, ndens_p, ion, phi, yfrac, zfrac, y2afrac, y2bfrac, &rc, clumping);
     de = orc_electrondens(ndens_p, ion->h_av, ion->he_av);
 
     coldensh_cell = coldens(path, ion->h[0], ndens_p, (1.0 - abu_he));
@@ -833,7 +839,7 @@ static void do_chemistry(const orc_tables *tb, const orc_step *st, orc_state *s,
     double ionhe0old = ion->he[0], ionhe1old = ion->he[1], ionhe2old = ion->he[2];
     double oldhav = ion->h_av[0], oldhe0av = ion->he_av[0], oldhe1av = ion->he_av[1];
 
-    orc_doric(dt, de, ndens_p, ion, phi, yfrac, zfrac, y2afrac, y2bfrac, &rc, st->clumping);
+    orc_doric(dt, de, ndens_p, ion, phi, yfrac, zfrac, y2afrac, y2bfrac, &rc, clumping);
 
     ion->h[0] = (ion->h[0] + ionh0old) / 2.0;
     ion->h[1] = (ion->h[1] + ionh1old) / 2.0;

@@ -57,8 +57,36 @@ def cooling_tables():
     return np.concatenate(cols), float(temp[0]), float(temp[1]) - float(temp[0])
 
 
+KEEP_OUT = ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av", "photon_loss_all",
+            "sum_nbox_all", "reccoef", "coldensh_out", "coldenshe_out"]
+
+
+def lls_case():
+    """use_LLS = .true. build (type_of_LLS = 1: the same Lyman-limit-system column in every cell,
+    evolve_point.F90:177-180), heating on, two sources; calls 1 and 2."""
+    subprocess.run([str(HERE / "ref_build.sh"), "16", "lls"], check=True)
+    srcs = [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]
+    run = refrun.run_reference(16, srcs, isothermal=False, steps_per_slice=1, lls=True, name="golden_N16_lls_heat_2src")
+    conv = refrun.parse_log(run)
+    out = {"conv_flags_per_call": np.array([len(c) for c in conv], dtype=np.int32)}
+    for call in (1, 2):
+        tin = refrun.read_records(run / "results" / f"tap_{call:04d}_in.bin")
+        tout = refrun.read_records(run / "results" / f"tap_{call:04d}_out.bin")
+        for k, v in tin.items():
+            out[f"c{call}_in_{k}"] = v
+        for k in KEEP_OUT:
+            out[f"c{call}_out_{k}"] = tout[k]
+        out[f"c{call}_conv_flags"] = np.array(conv[call - 1], dtype=np.int32)
+    np.savez_compressed(GOLD / "tap_N16_lls_heat_2src.npz", **out)
+    print("wrote tap_N16_lls_heat_2src.npz", [len(c) for c in conv])
+    shutil.rmtree(run)
+
+
 def main():
     GOLD.mkdir(parents=True, exist_ok=True)
+    if sys.argv[1:] == ["lls"]:
+        return lls_case()
+    lls_case()
     for mesh in sorted({c[1] for c in CASES}):
         subprocess.run([str(HERE / "ref_build.sh"), str(mesh)], check=True)
 

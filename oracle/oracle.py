@@ -80,7 +80,8 @@ class CStep(C.Structure):
                 ("isothermal", C.c_int), ("temper_val", C.c_double), ("clumping", C.c_float),
                 ("nsrc", C.c_int), ("srcpos", _ip), ("normflux", _dp), ("s_star", C.c_double),
                 ("normflux_pl", _dp), ("normflux_qpl", _dp), ("pl_s_star", C.c_double), ("qpl_s_star", C.c_double),
-                ("ndens", _dp), ("rc", RecCoef)]
+                ("ndens", _dp), ("rc", RecCoef),
+                ("use_lls", C.c_int), ("coldensh_lls", C.c_double), ("lls_grid", _fp), ("clumping_grid", _fp)]
 
 
 class CState(C.Structure):
@@ -158,7 +159,7 @@ class Step:
 
     def __init__(self, mesh, dr, vol, zred, H0, Omega0, isothermal, temper_val, clumping, srcpos,
                  normflux, s_star, ndens, reccoef, normflux_pl=None, normflux_qpl=None, pl_s_star=1.0,
-                 qpl_s_star=1.0):
+                 qpl_s_star=1.0, coldensh_lls=None, lls_grid=None, clumping_grid=None):
         self.srcpos = np.ascontiguousarray(srcpos, dtype=np.int32).reshape(-1)
         self.normflux = np.ascontiguousarray(normflux, dtype=np.float64).reshape(-1)
         self.ndens = np.ascontiguousarray(ndens, dtype=np.float64).reshape(-1)
@@ -180,6 +181,11 @@ class Step:
         c.pl_s_star, c.qpl_s_star = float(pl_s_star), float(qpl_s_star)
         c.ndens = _p(self.ndens)
         c.rc = RecCoef.from_array(reccoef)
+        self.lls_grid = None if lls_grid is None else np.ascontiguousarray(lls_grid, dtype=np.float32).reshape(-1)
+        self.clumping_grid = None if clumping_grid is None else np.ascontiguousarray(clumping_grid, dtype=np.float32).reshape(-1)
+        c.use_lls = int(coldensh_lls is not None or lls_grid is not None)
+        c.coldensh_lls = 0.0 if coldensh_lls is None else float(coldensh_lls)
+        c.lls_grid, c.clumping_grid = _p(self.lls_grid, _fp), _p(self.clumping_grid, _fp)
         self.c = c
         self.ncell = int(np.prod(mesh))
         self.isothermal = bool(isothermal)
@@ -189,7 +195,8 @@ class Step:
         return cls(t["mesh"], t["dr"], t["vol"][0], t["zred"][0], t["H0"][0], t["Omega0"][0],
                    t["isothermal"][0], t["temper_val"][0], t["clumping"][0], t["srcpos"], t["NormFlux"],
                    t["S_star"][0], t["ndens"], t["reccoef"], t.get("NormFluxPL"), t.get("NormFluxQPL"),
-                   t["pl_S_star"][0] if "pl_S_star" in t else 1.0, t["qpl_S_star"][0] if "qpl_S_star" in t else 1.0)
+                   t["pl_S_star"][0] if "pl_S_star" in t else 1.0, t["qpl_S_star"][0] if "qpl_S_star" in t else 1.0,
+                   coldensh_lls=t["coldensh_LLS"][0] if "coldensh_LLS" in t else None)
 
 
 class State:

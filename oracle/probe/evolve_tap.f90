@@ -14,6 +14,8 @@ subroutine evolve3d_tap(time, dt, restart) bind(C, name="__wrap__QMevolvePevolve
   use sizes, only: mesh
   use grid, only: dr, vol
   use material, only: ndens, xh, xhe, temperature_grid, isothermal, temper_val, clumping
+  use material, only: coldensh_LLS
+  use c2ray_parameters, only: use_LLS
   use sourceprops, only: NumSrc, srcpos, NormFlux
   use radiation_sed_parameters, only: S_star
 #ifdef PL
@@ -75,6 +77,7 @@ subroutine evolve3d_tap(time, dt, restart) bind(C, name="__wrap__QMevolvePevolve
   call put_i(u, "isothermal", (/iso/), 1)
   call put_d(u, "temper_val", (/temper_val/), 1)
   call put_f(u, "clumping", (/clumping/), 1)
+  if (use_LLS) call put_d(u, "coldensh_LLS", (/coldensh_LLS/), 1)
   call put_d(u, "reccoef", (/arech0, brech0, areche0, breche0, oreche0, areche1, breche1, &
        treche1, colli_HI, colli_HeI, colli_HeII, v/), 12)
   call put_d(u, "ndens", ndens, size(ndens))

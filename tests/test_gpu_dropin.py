@@ -19,6 +19,7 @@ sys.path.insert(0, str(ROOT / "oracle"))
 
 
 @pytest.mark.parametrize("iso,pl,sources", [
+    (False, "lls", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),   # use_LLS = .true. build
     (False, False, [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     (True, False, [(8, 8, 8, 1e55)]),
     # the -DPL -DQUASARS build (the flags of the reference's production targets, Makefile:185-186,207-208)
@@ -26,12 +27,13 @@ sys.path.insert(0, str(ROOT / "oracle"))
 ])
 def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, sources):
     import refrun
-    ref, hip = refrun.ref_binary(16, "test", pl=pl), refrun.ref_binary(16, "hip", pl=pl)
+    lls, pl = pl == "lls", pl is True
+    ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, "hip", pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "")
-    r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl)
-    r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="hip", name=f"dropin_hip_{tag}", pl=pl)
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "")
+    r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl, lls=lls)
+    r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="hip", name=f"dropin_hip_{tag}", pl=pl, lls=lls)
     files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
     assert len(files) >= 15, files
     for f in files:

@@ -452,3 +452,93 @@ def test_power_law_and_quasar_seds_vs_reference(pkg, gold):
     ev2 = pkg.Evolve(mesh, tables, device=0)
     n2 = ev2.evolve3D(0.0, float(i2["dt"][0]), 0, mat, grid, src, cosmo)
     assert n2 == len(o2["conv_flags"]) and np.array_equal(mat.xh, o2["xh"]) and np.array_equal(mat.xhe, o2["xhe"])
+
+
+@pytest.mark.parametrize("call", [1, 2])
+def test_lyman_limit_systems_vs_reference(pkg, tables, gold, call):
+    """use_LLS = .true. build of the reference (type_of_LLS = 1, tau_LLS ~ 0.15 per cell): whole
+    evolve3D calls with heating, bit-identical (evolve_point.F90:177-180)."""
+    i, o = tap_case(gold("tap_N16_lls_heat_2src.npz"), call)
+    mesh, mat, grid, src, cosmo = make_inputs(pkg, i)
+    mat.use_LLS, mat.coldensh_LLS = True, float(i["coldensh_LLS"][0])
+    ev = pkg.Evolve(mesh, tables, device=0)
+    niter = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
+    assert niter == len(o["conv_flags"]) and ev.conv_flags == [int(x) for x in o["conv_flags"]]
+    got = {"xh": mat.xh, "xhe": mat.xhe, "temperature": mat.temperature_grid, **ev.rates, **ev.iter_state}
+    for k in ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av"]:
+        assert np.array_equal(got[k], o[k]), k
+    cols = ev.engine.download_columns()
+    assert np.array_equal(cols["coldensh_out"], o["coldensh_out"])
+    assert np.array_equal(cols["coldenshe_out"], o["coldenshe_out"])
+
+
+@pytest.mark.parametrize("iso", [True, False])
+def test_position_dependent_lls_and_clumping_vs_oracle(pkg, orc, otables, tables, iso):
+    """type_of_LLS = 2 (LLS_point) and type_of_clumping = 5 (clumping_point): REAL(4) grids read per cell.
+    The reference's test target cannot load such grids, so the checker is the oracle (pinned for the
+    uniform LLS case above); 24^3, two sources, one outer iteration + photon-statistics sums."""
+    n, nsrc = 24, 2
+    rng = np.random.default_rng(77)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc))
+    x = 10.0 ** rng.uniform(-5, -0.3, nc)
+    xh = np.concatenate([1.0 - x, x])
+    xhe = np.concatenate([1.0 - x, 0.8 * x, 0.2 * x])
+    temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.2, nc))).astype(np.float32), 3)
+    srcpos = np.array([[1, n, n // 2], [n // 2, 3, n]], dtype=np.int32)
+    flux = np.array([3e6, 1e7])
+    lls = (10.0 ** rng.uniform(15.0, 17.5, nc)).astype(np.float32)
+    clump = (1.0 + 4.0 * rng.random(nc)).astype(np.float32)
+    mat = pkg.Material(ndens, xh, xhe, temp, iso, 1.0e4, 1.0, hp.reccoef(1.0e4), clumping_grid=clump, use_LLS=True,
+                       LLS_grid=lls)
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, flux, 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, tables)
+    e.begin_step()
+    e.set_rates_to_zero()
+    e.pass_sources(1, 1)
+    rates = e.download_rates()
+    cols = e.download_columns()
+    st = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens,
+                  hp.reccoef(1.0e4), lls_grid=lls, clumping_grid=clump)
+    s = orc.State(st, xh, xhe, temp)
+    orc.begin_step(s)
+    orc.pass_all_sources(otables, st, s)
+    assert np.array_equal(cols["coldensh_out"], s.coldensh_out)
+    for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)] + ([] if iso else [("phiheat", s.phiheat)]):
+        assert np.array_equal(rates[k], ref), k
+    # without the fog the columns must differ (the option is really on)
+    st0 = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens,
+                   hp.reccoef(1.0e4))
+    s0 = orc.State(st0, xh, xhe, temp)
+    orc.begin_step(s0)
+    orc.pass_all_sources(otables, st0, s0)
+    assert not np.array_equal(s0.coldensh_out, s.coldensh_out)
+    dt = 1.0e6 * hp.YEAR
+    conv = e.global_pass(dt)
+    conv_ref = orc.global_pass(otables, st, s, dt)
+    it = e.download_iter_state()
+    for k in ["xh_av", "xhe_av", "xh_intermed", "xhe_intermed"]:
+        assert np.array_equal(it[k], getattr(s, k)), k
+    assert conv == conv_ref
+    conv0 = orc.global_pass(otables, st0, s0, dt)
+    assert not np.array_equal(s0.xh_av, s.xh_av)
+    # recombinations with the clumping grid (photonstatistics.f90:175-193): linear in the grid, and a
+    # grid of ones is the scalar clumping = 1
+    rc = hp.reccoef(1.0e4)
+    tot = e.total_rates(dt, rc)
+    mat.clumping_grid = 2.0 * clump
+    e.set_step(mat, grid, cosmo)
+    tot2 = e.total_rates(dt, rc)
+    assert tot2[0] == 2.0 * tot[0] and tot2[2] == 2.0 * tot[2] and tot2[1] == tot[1]
+    mat.clumping_grid = np.ones(nc, dtype=np.float32)
+    e.set_step(mat, grid, cosmo)
+    tot1 = e.total_rates(dt, rc)
+    mat.clumping_grid = None
+    e.set_step(mat, grid, cosmo)
+    assert np.array_equal(e.total_rates(dt, rc), tot1) and tot1[0] < tot[0]
+    e.close()

@@ -100,3 +100,19 @@ def test_evolve3d_with_power_law_and_quasar_seds(orc, pkg, gold):
     for k, attr in {"xh": "xh", "xhe": "xhe", "temperature": "temperature", "phih_grid": "phih", "phihe_grid": "phihe",
                     "phiheat": "phiheat", "xh_av": "xh_av", "xhe_av": "xhe_av", "photon_loss_all": "photon_loss"}.items():
         assert np.array_equal(getattr(s, attr), o[k]), k
+
+
+def test_evolve3d_with_lyman_limit_systems(orc, otables, gold):
+    """use_LLS = .true. build of the reference (type 1: one LLS column per cell added to the incoming
+    HI column, evolve_point.F90:177-180): two whole calls, bit-identical."""
+    for call in (1, 2):
+        i, o = tap_case(gold("tap_N16_lls_heat_2src.npz"), call)
+        assert float(i["coldensh_LLS"][0]) > 1e16
+        st = orc.Step.from_tap(i)
+        s = orc.State(st, i["xh"], i["xhe"], i["temperature"])
+        niter = orc.evolve3d(otables, st, s, float(i["dt"][0]))
+        assert niter == len(o["conv_flags"]) and s.conv_flags == [int(x) for x in o["conv_flags"]]
+        for k, a in (("xh", s.xh), ("xhe", s.xhe), ("temperature", s.temperature), ("phih_grid", s.phih),
+                     ("phihe_grid", s.phihe), ("phiheat", s.phiheat), ("coldensh_out", s.coldensh_out),
+                     ("coldenshe_out", s.coldenshe_out)):
+            assert np.array_equal(a, o[k]), (call, k)
