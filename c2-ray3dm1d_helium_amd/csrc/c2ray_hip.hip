@@ -305,11 +305,21 @@ template <bool HEAT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK, MULTI ? 2 : (HEAT ? 3 : 5))
 k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
         const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
-        SedSet ss, double *__restrict__ rates) {
+        SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles) {
   const size_t nc = g.ncell;
-  const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (q >= nc) return;
-  const int i = (int)(q % g.n1), j = (int)((q / g.n1) % g.n2), k = (int)(q / ((size_t)g.n1 * g.n2));
+  // One block = a tile of 8 x 8 x 4 cells: a wave is an 8 x 8 patch in (i,j), the four waves are four
+  // consecutive k.  (Neighbouring cells see similar optical depths, so the lanes of a patch diverge less
+  // and gather from fewer table lines than 64 consecutive i; and with sub-boxes much smaller than the
+  // mesh a patch keeps ~(w/(w+7))^2 of its lanes busy for a box of width w instead of w/(w+63).)
+  // `tiles`, when given, lists the tiles that intersect a sub-box of the batch (built on the host): the
+  // launch then holds only blocks with work, which keeps enough heavy waves resident per SIMD.
+  const int ti = (g.n1 + 7) >> 3, tj = (g.n2 + 7) >> 3;
+  const int tile = tiles ? tiles[blockIdx.x] : (int)blockIdx.x;
+  const int bi = tile % ti, bj = (tile / ti) % tj, bk = tile / (ti * tj);
+  const int lane = threadIdx.x & 63;
+  const int i = bi * 8 + (lane & 7), j = bj * 8 + (lane >> 3), k = bk * 4 + (threadIdx.x >> 6);
+  if (i >= g.n1 || j >= g.n2 || k >= g.n3) return;
+  const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
   const double nd = ndens[q];
   const double h0 = dmax(xh_av[q], epsilon), h1 = dmax(xh_av[q + nc], epsilon);
   const double he0 = dmax(xhe_av[q], epsilon), he1 = dmax(xhe_av[q + nc], epsilon);
@@ -608,6 +618,8 @@ struct c2r_ctx {
   double *d_col = nullptr;
   size_t col_slots = 0;
   double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
+  int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr}; // tile lists of the rates launches (h: pinned)
+  std::vector<unsigned char> tile_mark;
   int blocks_total = 0;            // blocks of all shells 0..smax
   std::vector<int> block_base;     // first block of shell s in a partial-sum row
   double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
@@ -662,12 +674,26 @@ static int fail(c2r_ctx *c, const char *fmt, ...) {
 extern "C" const char *c2r_last_error(const c2r_ctx *c) { return c ? c->err.c_str() : "null context"; }
 extern "C" const char *c2r_create_error(void) { return g_create_error.c_str(); }
 
+// Zero a device range in pieces of at most 1 GiB.  (One hipMemset over more than 16 GiB -- a batch of 16
+// scratch slots at 256^3, or any batch at 512^3 -- left the tail of the range untouched on ROCm 7.2;
+// found because results then depended on the batch size.)
+static hipError_t zero_device(void *ptr, size_t bytes, hipStream_t stream) {
+  const size_t piece = (size_t)1 << 30;
+  char *p = static_cast<char *>(ptr);
+  for (size_t off = 0; off < bytes; off += piece) {
+    hipError_t e = hipMemsetAsync(p + off, 0, std::min(piece, bytes - off), stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 static int alloc_col(c2r_ctx *c) {
   if (c->d_col && c->col_slots >= (size_t)c->batch) return 0;
   if (c->d_col) HIPCHK(c, hipFree(c->d_col));
   c->d_col = nullptr;
   HIPCHK(c, hipMalloc(&c->d_col, sizeof(double) * 6 * c->g.colsize * c->batch * 2));
-  HIPCHK(c, hipMemset(c->d_col, 0, sizeof(double) * 6 * c->g.colsize * c->batch * 2));
+  HIPCHK(c, zero_device(c->d_col, sizeof(double) * 6 * c->g.colsize * c->batch * 2, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->col_slots = c->batch;
   return 0;
 }
@@ -727,13 +753,21 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   c->rates_count = 4 * nc + C2R_NFREQ + 1;
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
-  CR(hipMemset(c->d_rates, 0, sizeof(double) * c->rates_count)); // phih_grid = 0 for initial output (evolve_data.F90:77,80)
+  CR(zero_device(c->d_rates, sizeof(double) * c->rates_count, nullptr));
+  CR(hipDeviceSynchronize()); // phih_grid = 0 for initial output (evolve_data.F90:77,80)
   // block bookkeeping of the shells 0..smax
   c->block_base.assign(c->g.smax + 2, 0);
   for (int s = 0; s <= c->g.smax; s++)
     c->block_base[s + 1] = c->block_base[s] + (int)((shell_count(s) + BLOCK - 1) / BLOCK);
   c->blocks_total = c->block_base[c->g.smax + 1];
   CR(hipMalloc(&c->d_loss_partial, sizeof(double) * (size_t)c->blocks_total * MAXB));
+  {
+    const size_t ntiles = (size_t)((mesh[0] + 7) / 8) * ((mesh[1] + 7) / 8) * ((mesh[2] + 3) / 4);
+    for (int k = 0; k < 2; k++) {
+      CR(hipMalloc(&c->d_tiles[k], sizeof(int) * ntiles));
+      CR(hipHostMalloc(&c->h_tiles[k], sizeof(int) * ntiles));
+    }
+  }
   CR(hipMalloc(&c->d_loss_acc, sizeof(double) * MAXB));
   CR(hipHostMalloc(&c->h_loss, sizeof(double) * MAXB));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
@@ -758,6 +792,10 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
+  for (int k = 0; k < 2; k++) {
+    if (c->d_tiles[k]) (void)hipFree(c->d_tiles[k]);
+    if (c->h_tiles[k]) (void)hipHostFree(c->h_tiles[k]);
+  }
   if (c->h_conv) (void)hipHostFree(c->h_conv);
   if (c->h_stat) (void)hipHostFree(c->h_stat);
   for (auto &ev : c->ev)
@@ -1028,7 +1066,7 @@ extern "C" int c2r_end_step(c2r_ctx *c) {
 extern "C" int c2r_set_rates_to_zero(c2r_ctx *c) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemsetAsync(c->d_rates, 0, sizeof(double) * c->rates_count, c->stream));
+  HIPCHK(c, zero_device(c->d_rates, sizeof(double) * c->rates_count, c->stream));
   std::memset(c->photon_loss, 0, sizeof c->photon_loss);
   c->sum_nbox = 0;
   return 0;
@@ -1216,10 +1254,55 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
     }
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[set], 0));
     if (c->timing) HIPCHK(c, hipEventRecord(e_r0, c->stream2));
-    const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
+    // tiles (8 x 8 x 4 cells) that intersect the final sub-box of some source of the batch
+    const int nt1 = (g.n1 + 7) / 8, nt2 = (g.n2 + 7) / 8, nt3 = (g.n3 + 3) / 4;
+    int nblk = nt1 * nt2 * nt3;
+    const int *d_tiles = nullptr;
+    {
+      bool full = false;
+      for (int b = 0; b < nb && !full; b++) {
+        full = true;
+        for (int d = 0; d < 3; d++) full = full && (run[b].last_r[d] - run[b].last_l[d] + 1 >= mesh[d]);
+      }
+      if (!full) {
+        // the pinned list of this set may still feed the copy queued two batches ago
+        if (c->set_busy[set]) HIPCHK(c, hipEventSynchronize(c->ev_rates_done[set]));
+        std::vector<unsigned char> &mark = c->tile_mark;
+        mark.assign((size_t)nblk, 0);
+        std::vector<unsigned char> cov[3];
+        const int tsz[3] = {8, 8, 4}, ntd[3] = {nt1, nt2, nt3};
+        for (int b = 0; b < nb; b++) {
+          const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
+          for (int d = 0; d < 3; d++) {
+            cov[d].assign((size_t)ntd[d], 0);
+            for (int o = run[b].last_l[d]; o <= run[b].last_r[d]; o++) {
+              int x = (p[d] - 1 + o) % mesh[d];
+              if (x < 0) x += mesh[d];
+              cov[d][x / tsz[d]] = 1;
+            }
+          }
+          for (int tk = 0; tk < nt3; tk++) {
+            if (!cov[2][tk]) continue;
+            for (int tj_ = 0; tj_ < nt2; tj_++) {
+              if (!cov[1][tj_]) continue;
+              unsigned char *row = &mark[((size_t)tk * nt2 + tj_) * nt1];
+              for (int ti_ = 0; ti_ < nt1; ti_++) row[ti_] |= cov[0][ti_];
+            }
+          }
+        }
+        int *list = c->h_tiles[set];
+        int cnt = 0;
+        for (int t = 0; t < nblk; t++)
+          if (mark[t]) list[cnt++] = t;
+        if (cnt == 0) { list[0] = 0; cnt = 1; }
+        HIPCHK(c, hipMemcpyAsync(c->d_tiles[set], list, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, c->stream2));
+        d_tiles = c->d_tiles[set];
+        nblk = cnt;
+      }
+    }
 #define C2R_LAUNCH_RATES(H, M)                                                                               \
   hipLaunchKernelGGL((k_rates<H, M>), dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens,  \
-                     c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates)
+                     c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates, d_tiles)
     if (c->isothermal) {
       if (multi) C2R_LAUNCH_RATES(false, true); else C2R_LAUNCH_RATES(false, false);
     } else {

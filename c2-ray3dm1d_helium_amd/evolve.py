@@ -277,6 +277,13 @@ class HipEngine:
         self._chk(self.lib.c2r_download_rates(self.h, _dp(phih), _dp(phihe), _dp(phiheat), _dp(loss), C.byref(nbox)))
         return dict(phih_grid=phih, phihe_grid=phihe, phiheat=phiheat, photon_loss=loss, sum_nbox=nbox.value)
 
+    def get_loss(self):
+        """(photon_loss(1:47), sum_nbox) of this rank's last pass, without touching the grids."""
+        loss = np.empty(47)
+        nbox = C.c_int(0)
+        self._chk(self.lib.c2r_get_loss(self.h, _dp(loss), C.byref(nbox)))
+        return loss, int(nbox.value)
+
     def download_iter_state(self):
         n = self.ncell
         a, b, c, d = np.empty(2 * n), np.empty(3 * n), np.empty(2 * n), np.empty(3 * n)

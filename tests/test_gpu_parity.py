@@ -542,3 +542,65 @@ def test_position_dependent_lls_and_clumping_vs_oracle(pkg, orc, otables, tables
     e.set_step(mat, grid, cosmo)
     assert np.array_equal(e.total_rates(dt, rc), tot1) and tot1[0] < tot[0]
     e.close()
+
+
+def _pass_result(pkg, tables, mat, grid, src, cosmo, n, batch, first=1, stride=1, iters=2):
+    e = pkg.HipEngine((n, n, n), 0)
+    e.set_tables(tables)
+    e.set_step(mat, grid, cosmo)
+    e.set_sources(src)
+    e.upload_state(mat)
+    e.set_batch(batch)
+    e.begin_step()
+    out = []
+    for _ in range(iters):
+        e.set_rates_to_zero()
+        e.pass_sources(first, stride)
+        r = e.download_rates()
+        conv = e.global_pass(1.0e7 * pkg.hostphys.YEAR)
+        out.append((r["phih_grid"], r["phihe_grid"], r["photon_loss"][0], r["sum_nbox"], conv))
+    e.close()
+    return out
+
+
+def test_many_faint_sources_batch_invariance_256(pkg, tables):
+    """BASELINE configs[3]-like: 256^3 log-normal density, 1024 seeded sources of 1e52..1e54 photons/s in
+    neutral gas, the 128 sources of rank 0 of 8.  Sub-boxes stop early (5-6 rounds), so the rates launches
+    run on host-built tile lists.  Batches of 4 and of 16 sources (scratch of 6.5 and 26 GB: the second is
+    beyond the 16 GiB a single hipMemset handled) must give identical bits."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import bench_config4
+    n = 256
+    mat, grid, src, cosmo = bench_config4.config4_inputs(pkg, n, 1024)
+    a = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 4, 1, 8)
+    b = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 16, 1, 8)
+    for x, y in zip(a, b):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        assert x[2:] == y[2:]
+    assert 128 * 3 < a[0][3] < 128 * 13 and a[0][4] > 0          # boxes really stopped early
+
+
+def test_512_cube_scratch_beyond_16GiB(pkg, tables):
+    """BASELINE configs[4]'s mesh: one 512^3 slot of column scratch is 6.5 GB, so any batch is beyond
+    16 GiB.  Two box-filling sources, batch 1 vs batch 2: identical bits, and exact linearity in the flux."""
+    n = 512
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = np.full(nc, hp.test_density(zred))
+    x0 = 1.0e-3 * (1.0 + 0.5 * np.sin(np.arange(nc, dtype=np.float64) * 1.0e-3))
+    xh = np.concatenate([x0, 1.0 - x0])
+    xhe = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
+    mat = pkg.Material(ndens, xh, xhe, None, True, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(np.array([[100, 200, 300], [512, 1, 256]], dtype=np.int32), np.array([1e8, 3e8]), 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    a = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 1, iters=1)[0]
+    b = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 2, iters=1)[0]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    assert a[3] == 2 * 26 and np.all(a[0] > 0)                     # 26 sub-boxes each: the whole mesh
+    src.NormFlux = 2.0 * src.NormFlux
+    c = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 2, iters=1)[0]
+    assert np.array_equal(c[0], 2.0 * a[0]) and np.array_equal(c[1], 2.0 * a[1])

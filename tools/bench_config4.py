@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Production-like workload (BASELINE configs[3]): 256^3 log-normal density
+(sigma_ln = 1, seed 2024), 1024 seeded sources with log-uniform luminosities 1e52..1e54 photons/s, gas
+neutral at the start, one whole evolve3D call (all outer iterations to convergence).
+
+On one GPU this plays rank `--rank` of `--ranks`: it sweeps sources rank+1, rank+1+ranks, ... only (the other
+ranks' rate contributions are missing, so the ionisation history is that of a 1/ranks-luminosity run --
+fine for timing the per-GPU work of a sharded run).  With --ranks 1 it is the complete problem.
+
+Not the headline bench (bench.py); prints one JSON line with per-phase times.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+
+def config4_inputs(pkg, n=256, nsrc=1024, seed=2024, heating=False):
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    rng = np.random.default_rng(seed)
+    ln = rng.normal(0.0, 1.0, nc)
+    ndens = hp.test_density(zred) * np.exp(ln - 0.5)          # mean-preserving log-normal
+    srcpos = rng.integers(1, n + 1, size=(nsrc, 3)).astype(np.int32)
+    flux = 10.0 ** rng.uniform(52.0, 54.0, nsrc) / 1.0e48
+    eps = 1.0e-20
+    xh = np.concatenate([np.full(nc, 1.0 - eps), np.full(nc, eps)])
+    xhe = np.concatenate([np.full(nc, 1.0 - 2 * eps), np.full(nc, eps), np.full(nc, eps)])
+    temp = np.full(3 * nc, 1.0e4, dtype=np.float32) if heating else None
+    mat = pkg.Material(ndens, xh, xhe, temp, not heating, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, flux, 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    return mat, grid, src, cosmo
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mesh", type=int, default=256)
+    ap.add_argument("--sources", type=int, default=1024)
+    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--max-iter", type=int, default=40)
+    ap.add_argument("--dt-years", type=float, default=1.0e7)
+    ap.add_argument("--heating", action="store_true")
+    a = ap.parse_args()
+    pkg = ge.load_package()
+    n = a.mesh
+    mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating)
+    e = pkg.HipEngine((n, n, n), 0)
+    e.set_tables(pkg.RadiationTables.load())
+    e.set_step(mat, grid, cosmo)
+    e.set_sources(src)
+    e.upload_state(mat)
+    e.set_batch(a.batch)
+    e.enable_timing(True)
+    dt = a.dt_years * pkg.hostphys.YEAR
+    mine = len(range(a.rank, a.sources, a.ranks))
+    e.begin_step()
+    conv_criterion = min(int(2.5e-4 * n ** 3), a.sources)
+    hist = []
+    t_all = time.perf_counter()
+    niter, conv = 0, n ** 3
+    while not (conv < conv_criterion and niter > 1) and niter < a.max_iter:
+        niter += 1
+        t0 = time.perf_counter()
+        e.set_rates_to_zero()
+        e.pass_sources(1 + a.rank, a.ranks)
+        t1 = time.perf_counter()
+        conv = e.global_pass(dt)
+        t2 = time.perf_counter()
+        tm = e.timing()
+        hist.append({"iter": niter, "pass_ms": 1e3 * (t1 - t0), "chem_ms": 1e3 * (t2 - t1), "sweep_kernel_ms": tm.sweep_ms,
+                     "rates_kernel_ms": tm.rates_ms, "cells_swept": int(tm.cells_swept), "sweep_launches": tm.sweep_launches,
+                     "rates_launches": tm.rates_launches, "nonconv": int(conv), "sum_nbox": int(e.get_loss()[1])})
+    wall = time.perf_counter() - t_all
+    swept = sum(h["cells_swept"] for h in hist)
+    out = {"workload": f"configs[3]-like: {n}^3 log-normal density, {a.sources} sources, rank {a.rank} of {a.ranks} "
+                       f"({mine} sources on this GPU), neutral start, dt = {a.dt_years:g} yr, batch {a.batch}",
+           "niter": niter, "wall_s": wall, "swept_cell_updates_per_s": swept / wall,
+           "nominal_cell_updates_per_s": n ** 3 * mine * niter / wall,
+           "mean_subboxes_per_source": float(np.mean([h["sum_nbox"] for h in hist])) / max(1, mine),
+           "iterations": hist}
+    print(json.dumps(out))
+    e.close()
+
+
+if __name__ == "__main__":
+    main()
