@@ -148,7 +148,7 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("C2R_BENCH_FORCE_COMM"):   # the env knob rehearses the N > 1 code path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         comm = pkg.parallel.TorchComm()
@@ -172,9 +172,10 @@ def main():
 
     def step():
         e.set_rates_to_zero()
-        e.pass_sources(1 + rank, world)
         if comm is not None:
-            comm.allreduce_rates(e)
+            comm.pass_and_allreduce(e)   # the sum over ranks overlaps the pass slab by slab (parallel.py)
+        else:
+            e.pass_sources(1, 1)
         return e.global_pass(dt)
 
     def barrier():

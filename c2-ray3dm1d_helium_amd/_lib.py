@@ -48,6 +48,10 @@ SYMBOLS = {
     "c2r_begin_step": (C.c_int, [C.c_void_p]),
     "c2r_set_rates_to_zero": (C.c_int, [C.c_void_p]),
     "c2r_pass_sources": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "c2r_pass_sources_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "c2r_pass_slab_count": (C.c_int, [C.c_void_p]),
+    "c2r_pass_wait_slab": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "c2r_pass_sources_end": (C.c_int, [C.c_void_p]),
     "c2r_do_source": (C.c_int, [C.c_void_p, C.c_int]),
     "c2r_global_pass": (C.c_int, [C.c_void_p, C.c_double, _ip]),
     "c2r_end_step": (C.c_int, [C.c_void_p]),

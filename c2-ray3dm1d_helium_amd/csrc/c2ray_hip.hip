@@ -305,7 +305,7 @@ template <bool HEAT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK, MULTI ? 2 : (HEAT ? 3 : 5))
 k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
         const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
-        SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles) {
+        SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles, int tile_base) {
   const size_t nc = g.ncell;
   // One block = a tile of 8 x 8 x 4 cells, one wave = a 4 x 4 x 4 cube of it.  Neighbouring cells see
   // similar optical depths: the lanes of a cube mostly take the same branch of the bit-exact log (its
@@ -316,7 +316,7 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
   // `tiles`, when given, lists the tiles that intersect a sub-box of the batch (built on the host): the
   // launch then holds only blocks with work, which keeps enough heavy waves resident per SIMD.
   const int ti = (g.n1 + 7) >> 3, tj = (g.n2 + 7) >> 3;
-  const int tile = tiles ? tiles[blockIdx.x] : (int)blockIdx.x;
+  const int tile = tiles ? tiles[tile_base + blockIdx.x] : tile_base + (int)blockIdx.x;
   const int bi = tile % ti, bj = (tile / ti) % tj, bk = tile / (ti * tj);
   const int lane = threadIdx.x & 63;
   const int w_ = threadIdx.x >> 6;
@@ -652,6 +652,13 @@ struct c2r_ctx {
   // co-resident on the same SIMDs (the sweep is memory-bound, the rates kernel ALU-bound)
   unsigned rates_lds = 0;
 
+  // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
+  bool pass_open = false;
+  int pass_slabs = 0;
+  std::vector<int> slab_k;          // k-plane boundaries of the slabs
+  std::vector<hipEvent_t> ev_slab;
+  std::vector<hipEvent_t> pass_tev;
+
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   c2r_timing tm{};
@@ -791,7 +798,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_stateT, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump};
+                  c->d_rates_own, c->d_stateT, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
@@ -804,6 +811,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   for (auto &ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
+  for (auto &ev : c->ev_slab) (void)hipEventDestroy(ev);
   for (int i = 0; i < 2; i++) {
     if (c->ev_sweep_done[i]) (void)hipEventDestroy(c->ev_sweep_done[i]);
     if (c->ev_rates_done[i]) (void)hipEventDestroy(c->ev_rates_done[i]);
@@ -1114,8 +1122,14 @@ static int pool_event(c2r_ctx *c, hipEvent_t *out) {
 // high-priority stream, then ONE rates launch for the whole batch on the second stream; the next
 // batch's sweep overlaps it (scratch sets ping-pong).  Rates launches are ordered on their stream,
 // so the accumulation over sources keeps the reference's order.
-static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
+static int pass_finish(c2r_ctx *c);
+
+// nslab > 0: the caller wants to consume the rate grids slab by slab (z ranges) while later slabs are
+// still being computed: the rates launch of the LAST batch is cut into nslab launches, an event is
+// recorded after each, and the final synchronisation is left to pass_finish.
+static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->pass_open) return fail(c, "previous c2r_pass_sources_begin was not closed by c2r_pass_sources_end");
   if (alloc_col(c)) return 1;
   const Grid g = c->g;
   const size_t nc = g.ncell;
@@ -1140,6 +1154,16 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
     for (int a = 0; a < 4; a++) P.dst[a] = c->d_stateT + (size_t)a * nc;
     hipLaunchKernelGGL(k_transpose_ij, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 4 * g.n3), dim3(BLOCK), 0, c->stream, g, P);
     HIPCHK(c, hipGetLastError());
+  }
+  // slabs: tile layers (4 planes each) [slab_layer[s], slab_layer[s+1])
+  const int nt3_all = (g.n3 + 3) / 4;
+  const int ns_eff = nslab > 0 ? std::min(nslab, nt3_all) : 0;
+  c->slab_k.assign(1, 0);
+  for (int sidx = 1; sidx <= ns_eff; sidx++) c->slab_k.push_back(std::min(g.n3, 4 * (int)((long long)nt3_all * sidx / ns_eff)));
+  while (c->ev_slab.size() < (size_t)ns_eff) {
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_slab.push_back(e);
   }
   int bi = 0;
   for (size_t b0 = 0; b0 < mine.size(); b0 += c->batch, bi++) {
@@ -1304,12 +1328,32 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
       }
     }
 #define C2R_LAUNCH_RATES(H, M)                                                                               \
-  hipLaunchKernelGGL((k_rates<H, M>), dim3(nblk), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens,  \
-                     c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates, d_tiles)
-    if (c->isothermal) {
-      if (multi) C2R_LAUNCH_RATES(false, true); else C2R_LAUNCH_RATES(false, false);
-    } else {
-      if (multi) C2R_LAUNCH_RATES(true, true); else C2R_LAUNCH_RATES(true, false);
+  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens,  \
+                     c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates, d_tiles, base_)
+    const bool last_batch = b0 + c->batch >= mine.size();
+    const int pieces = (last_batch && ns_eff > 0) ? ns_eff : 1;
+    const int per_layer = nt1 * nt2;
+    for (int piece = 0; piece < pieces; piece++) {
+      // tiles of the layers [l0, l1): a contiguous range of tile ids, hence of the (sorted) list too
+      const int l0 = pieces == 1 ? 0 : c->slab_k[piece] / 4;
+      const int l1 = pieces == 1 ? nt3 : (c->slab_k[piece + 1] + 3) / 4;
+      int base_, cnt_;
+      if (d_tiles) {
+        const int *list = c->h_tiles[set];
+        base_ = (int)(std::lower_bound(list, list + nblk, l0 * per_layer) - list);
+        cnt_ = (int)(std::lower_bound(list, list + nblk, l1 * per_layer) - list) - base_;
+      } else {
+        base_ = l0 * per_layer;
+        cnt_ = (l1 - l0) * per_layer;
+      }
+      if (cnt_ > 0) {
+        if (c->isothermal) {
+          if (multi) C2R_LAUNCH_RATES(false, true); else C2R_LAUNCH_RATES(false, false);
+        } else {
+          if (multi) C2R_LAUNCH_RATES(true, true); else C2R_LAUNCH_RATES(true, false);
+        }
+      }
+      if (last_batch && ns_eff > 0) HIPCHK(c, hipEventRecord(c->ev_slab[piece], c->stream2));
     }
 #undef C2R_LAUNCH_RATES
     HIPCHK(c, hipGetLastError());
@@ -1329,14 +1373,27 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
     c->last_src = run[nb - 1].ns;
     for (int d = 0; d < 3; d++) { c->last_lo[d] = run[nb - 1].last_l[d]; c->last_hi[d] = run[nb - 1].last_r[d]; }
   }
+  // a rank without sources of its own still owes the caller its slab events
+  if (mine.empty())
+    for (int sidx = 0; sidx < ns_eff; sidx++) HIPCHK(c, hipEventRecord(c->ev_slab[sidx], c->stream2));
   // tail of the reduction buffer: photon_loss(1:47), sum_nbox
   double tail[C2R_NFREQ + 1];
   std::memcpy(tail, c->photon_loss, sizeof c->photon_loss);
   tail[C2R_NFREQ] = (double)c->sum_nbox;
   HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * nc, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
+  c->pass_tev = tev;
+  c->pass_open = true;
+  c->pass_slabs = ns_eff;
+  if (nslab > 0) return 0;
+  return pass_finish(c);
+}
+
+static int pass_finish(c2r_ctx *c) {
+  if (!c->pass_open) return 0;
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->set_busy[0] = c->set_busy[1] = false;
+  const std::vector<hipEvent_t> &tev = c->pass_tev;
   for (size_t i = 0; i + 3 < tev.size(); i += 4) {
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, tev[i], tev[i + 1]));
@@ -1344,6 +1401,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine) {
     HIPCHK(c, hipEventElapsedTime(&ms, tev[i + 2], tev[i + 3]));
     c->tm.rates_ms += ms;
   }
+  c->pass_open = false;
   return 0;
 }
 
@@ -1354,6 +1412,34 @@ extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
   std::vector<int> mine;
   for (int ns = first; ns <= c->nsrc; ns += stride) mine.push_back(ns);
   return pass_list(c, mine);
+}
+
+extern "C" int c2r_pass_sources_begin(c2r_ctx *c, int first, int stride, int nslab) {
+  if (!c) return 1;
+  if (check_ready(c, "c2r_pass_sources_begin")) return 1;
+  if (first < 1 || stride < 1 || nslab < 1) return fail(c, "c2r_pass_sources_begin: first=%d stride=%d nslab=%d", first, stride, nslab);
+  std::vector<int> mine;
+  for (int ns = first; ns <= c->nsrc; ns += stride) mine.push_back(ns);
+  return pass_list(c, mine, nslab);
+}
+
+extern "C" int c2r_pass_slab_count(c2r_ctx *c) { return c && c->pass_open ? c->pass_slabs : 0; }
+
+extern "C" int c2r_pass_wait_slab(c2r_ctx *c, int slab, size_t *first_cell, size_t *ncells) {
+  if (!c) return 1;
+  if (!c->pass_open || slab < 0 || slab >= c->pass_slabs) return fail(c, "c2r_pass_wait_slab: slab %d of %d (pass %s)", slab, c->pass_slabs, c->pass_open ? "open" : "not open");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->ev_slab[slab]));
+  const size_t plane = (size_t)c->g.n1 * c->g.n2;
+  if (first_cell) *first_cell = plane * (size_t)c->slab_k[slab];
+  if (ncells) *ncells = plane * (size_t)(c->slab_k[slab + 1] - c->slab_k[slab]);
+  return 0;
+}
+
+extern "C" int c2r_pass_sources_end(c2r_ctx *c) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  return pass_finish(c);
 }
 
 extern "C" int c2r_do_source(c2r_ctx *c, int ns) {

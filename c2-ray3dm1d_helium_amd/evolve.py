@@ -182,6 +182,7 @@ class HipEngine:
         dr = (C.c_double * 3)(*[float(x) for x in grid.dr])
         rc = _f64(mat.reccoef).reshape(-1)
         assert rc.size == 12
+        self.isothermal = bool(mat.isothermal)
         self._chk(self.lib.c2r_set_step(self.h, _dp(nd), dr, float(grid.vol), float(mat.clumping), float(cosmo.zred),
                                         float(cosmo.H0), float(cosmo.Omega0), int(bool(mat.isothermal)),
                                         float(mat.temper_val), _dp(rc)))
@@ -236,6 +237,20 @@ class HipEngine:
 
     def pass_sources(self, first=1, stride=1):
         self._chk(self.lib.c2r_pass_sources(self.h, int(first), int(stride)))
+
+    def pass_sources_begin(self, first=1, stride=1, nslab=8):
+        """Queue the pass and return at once; returns the number of slabs to wait for."""
+        self._chk(self.lib.c2r_pass_sources_begin(self.h, int(first), int(stride), int(nslab)))
+        return int(self.lib.c2r_pass_slab_count(self.h))
+
+    def pass_wait_slab(self, slab):
+        """Block until the rate grids of this slab are final; (first_cell, ncells) of every component."""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._chk(self.lib.c2r_pass_wait_slab(self.h, int(slab), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def pass_sources_end(self):
+        self._chk(self.lib.c2r_pass_sources_end(self.h))
 
     def do_source(self, ns):
         self._chk(self.lib.c2r_do_source(self.h, int(ns)))
@@ -402,8 +417,7 @@ class Evolve:
             niter += 1
             e.set_rates_to_zero()
             if numsrc > 0:
-                e.pass_sources(1 + comm.rank, comm.size)
-                comm.allreduce_rates(e)
+                comm.pass_and_allreduce(e)
             conv_flag = e.global_pass(dt)
             self.conv_flags.append(conv_flag)
         self.niter = niter

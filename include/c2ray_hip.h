@@ -109,6 +109,18 @@ int c2r_evolve3d(c2r_ctx *ctx, double dt, int *niter_out, int *conv_flags_out, i
 int c2r_begin_step(c2r_ctx *ctx);
 int c2r_set_rates_to_zero(c2r_ctx *ctx);
 int c2r_pass_sources(c2r_ctx *ctx, int first, int stride);
+/* The same pass, handing the rate grids over in nslab slabs of k-planes while later slabs are still being
+ * computed, so that a multi-rank host can start the sum over ranks (mpi_accumulate_grid_quantities,
+ * evolve.F90:505-548) of slab s while the device works on slabs s+1..:
+ *   c2r_pass_sources_begin  queues the whole pass and returns without waiting for the device
+ *   c2r_pass_slab_count     slabs of the open pass (<= nslab: at least one 4-plane tile layer each)
+ *   c2r_pass_wait_slab      blocks until phih/phihe/phiheat of slab `slab` hold this rank's final sums;
+ *                           the slab is cells [first_cell, first_cell + ncells) of every component grid
+ *   c2r_pass_sources_end    waits for the rest (photon_loss, sum_nbox, timing); must close every begin */
+int c2r_pass_sources_begin(c2r_ctx *ctx, int first, int stride, int nslab);
+int c2r_pass_slab_count(c2r_ctx *ctx);
+int c2r_pass_wait_slab(c2r_ctx *ctx, int slab, size_t *first_cell, size_t *ncells);
+int c2r_pass_sources_end(c2r_ctx *ctx);
 /* do_source(dt,ns1,niter) (evolve_source.F90:66-238) for the single source ns1 (1-based): trace it
  * and add its contribution to the rate grids, photon_loss(1) and sum_nbox. */
 int c2r_do_source(c2r_ctx *ctx, int ns);

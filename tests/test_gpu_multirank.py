@@ -14,7 +14,7 @@ from conftest import ROOT, tap_case
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pipelined=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
@@ -27,7 +27,13 @@ def _worker(rank, world, port, q):
     gold = lambda n: np.load(ROOT / "tests" / "golden" / n)
     i, o, mesh, mat, grid, src, cosmo = _inputs(pkg, gold, "tap_N16_heat_3src.npz", 2)
     torch.cuda.set_device(0)
-    ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), device=0, comm=pkg.parallel.TorchComm())
+    comm = pkg.parallel.TorchComm()
+    if not pipelined:   # whole-buffer all-reduce after the pass, the path CPU engines take
+        def plain(e, nslab=8):
+            e.pass_sources(1 + comm.rank, comm.size)
+            comm.allreduce_rates(e)
+        comm.pass_and_allreduce = plain
+    ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), device=0, comm=comm)
     n = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
     if rank == 0:
         q.put(dict(niter=n, xh=mat.xh, temp=mat.temperature_grid, nbox=ev.sum_nbox_all, loss=ev.photon_loss_all[0],
@@ -36,18 +42,29 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu(pkg, gold):
-    _, o = tap_case(gold("tap_N16_heat_3src.npz"), 2)
+def _run_two_ranks(pipelined, port):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, pipelined)) for r in range(2)]
     for p in procs:
         p.start()
     res = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return res
+
+
+def test_two_ranks_on_one_gpu(pkg, gold):
+    _, o = tap_case(gold("tap_N16_heat_3src.npz"), 2)
+    port = 29600 + (os.getpid() % 2000)
+    res = _run_two_ranks(True, port)
+    # the slab-pipelined sum (rates of slab s+1 computed while slab s is reduced) changes no bit against the
+    # whole-buffer all-reduce after the pass: two ranks, a + b == b + a
+    plain = _run_two_ranks(False, port + 1)
+    assert res["niter"] == plain["niter"] and res["nbox"] == plain["nbox"] and res["loss"] == plain["loss"]
+    for k in ("xh", "temp", "phih"):
+        assert np.array_equal(res[k], plain[k]), k
     n = 16 ** 3
     assert abs(res["niter"] - len(o["conv_flags"])) <= 2
     assert res["nbox"] == int(o["sum_nbox_all"][0])

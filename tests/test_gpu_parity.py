@@ -604,3 +604,44 @@ def test_512_cube_scratch_beyond_16GiB(pkg, tables):
     src.NormFlux = 2.0 * src.NormFlux
     c = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 2, iters=1)[0]
     assert np.array_equal(c[0], 2.0 * a[0]) and np.array_equal(c[1], 2.0 * a[1])
+
+
+@pytest.mark.parametrize("n,flux_exp", [(40, 7.0), (40, 4.3), (22, 6.5)])
+def test_slabwise_pass_equals_plain_pass(pkg, tables, n, flux_exp):
+    """c2r_pass_sources_begin / _wait_slab / _end (the rates launch of the last batch cut into slabs of
+    k-planes, for the overlapped sum over ranks) leaves the same bits as c2r_pass_sources: box-filling
+    sources (direct tile map), faint ones (host-built tile lists) and a mesh that is no multiple of 4."""
+    rng = np.random.default_rng(5)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc))
+    x = 10.0 ** rng.uniform(-4, -0.3, nc)
+    mat = pkg.Material(ndens, np.concatenate([1.0 - x, x]), np.concatenate([1.0 - x, 0.8 * x, 0.2 * x]), None, True,
+                       1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(rng.integers(1, n + 1, size=(5, 3)).astype(np.int32), 10.0 ** rng.uniform(flux_exp - 1, flux_exp, 5), 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, tables)
+    e.set_batch(2)          # three batches: only the last one is cut
+    e.begin_step()
+    e.set_rates_to_zero()
+    e.pass_sources(1, 1)
+    want = e.download_rates()
+    for nslab in (1, 3, 64):
+        e.set_rates_to_zero()
+        ns = e.pass_sources_begin(1, 1, nslab)
+        assert 1 <= ns <= min(nslab, (n + 3) // 4)
+        covered = 0
+        for sl in range(ns):
+            c0, cnt = e.pass_wait_slab(sl)
+            assert c0 == covered and cnt > 0 and cnt % (n * n) == 0
+            covered += cnt
+        assert covered == nc
+        e.pass_sources_end()
+        got = e.download_rates()
+        for k in ("phih_grid", "phihe_grid", "photon_loss"):
+            assert np.array_equal(got[k], want[k]), (nslab, k)
+        assert got["sum_nbox"] == want["sum_nbox"]
+    e.close()

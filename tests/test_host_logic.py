@@ -56,15 +56,14 @@ def test_python_host_loop_equals_reference(pkg, orc, otables, gold):
     class OneRank:
         rank, size = 0, 2  # size 2 forces the step-wise path; no partner: reduce is the identity
 
-        def allreduce_rates(self, e):
+        def pass_and_allreduce(self, e, nslab=8):
+            e.pass_sources(1, 1)  # every source on this single "rank"
             e.rates_buffer()
             e.rates_reduced()
 
     i, o, mesh, mat, grid, src, cosmo = _inputs(pkg, gold, "tap_N16_heat_3src.npz", 1)
     comm = OneRank()
     ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), engine=OracleEngine(mesh, otables), comm=comm)
-    # every source on this single "rank"
-    ev.engine.pass_sources = (lambda f=ev.engine.pass_sources: (lambda first=1, stride=1: f(1, 1)))()
     n = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
     assert n == len(o["conv_flags"]) and ev.conv_flags == [int(x) for x in o["conv_flags"]]
     assert np.array_equal(mat.xh, o["xh"]) and np.array_equal(mat.xhe, o["xhe"])
