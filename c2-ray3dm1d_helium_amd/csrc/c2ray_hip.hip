@@ -44,7 +44,7 @@ struct SrcInfo {
   double nflux;        // NormFlux(ns)
   double nflux_sed[2]; // NormFluxPL(ns), NormFluxQPL(ns) (-DPL / -DQUASARS builds), else 0
   int slot;            // scratch slot
-  int pad;
+  int exact;           // sweep: 1 = photon loss of every boundary cell, 0 = of a 1/16 sample (a lower bound)
 };
 struct BatchArgs {
   int n;
@@ -133,6 +133,15 @@ __device__ __forceinline__ double block_sum(double x, double *sh) {
   return r; // valid in thread 0
 }
 
+// path length of cinterp for an offset, without the corner work (column_density.f90:194,269,341)
+__device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
+  const int ia = idel < 0 ? -idel : idel, ja = jdel < 0 ? -jdel : jdel, ka = kdel < 0 ? -kdel : kdel;
+  const double di = (double)idel, dj = (double)jdel, dk = (double)kdel;
+  if (ka >= ja && ka >= ia) return sqrt((di * di + dj * dj) / (dk * dk) + 1.0);
+  if (ja >= ia && ja >= ka) return sqrt((di * di + dk * dk) / (dj * dj) + 1.0);
+  return sqrt(1.0 + (dj * dj + dk * dk) / (di * di));
+}
+
 // ---------------------------------------------------------------------------------------------
 // (i,j,k) -> (j,i,k) copies of the four state grids the sweep reads, so that the cells of a
 // shell's i-faces (fixed i, consecutive j) are consecutive in memory too.  32x32 tiles through LDS.
@@ -158,6 +167,66 @@ k_transpose_ij(Grid g, Ptr4 P) {
     const int j = j0 + tx, i = i0 + r;
     if (i < g.n1 && j < g.n2) dst[(size_t)j + (size_t)g.n2 * i] = tile[tx][r];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The photon loss through the surface of the current sub-box, in full, from the columns the sweep has
+// just stored: same thread <-> cell map, same expression and same block partial sums as k_sweep_shell
+// with S.exact = 1, for all shells [s_lo, s_hi] of the round in ONE launch (blockIdx.x counts the blocks
+// of those shells; block_base is the per-shell prefix).  Used when a sampled loss was not decisive.
+__global__ void __launch_bounds__(BLOCK)
+k_loss_exact(Grid g, BatchArgs ba, int s_lo, int s_hi, StepScalars sc, const double *__restrict__ col,
+             const BandData *__restrict__ bd, SedSet ss, const int *__restrict__ block_base,
+             double *__restrict__ loss_partial, int blocks_total) {
+  __shared__ double sh[BLOCK / 64];
+  const SrcInfo &S = ba.s[blockIdx.y];
+  const int B = block_base[s_lo] + (int)blockIdx.x;
+  int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_base[mid] <= B) lo = mid; else hi = mid - 1;
+  }
+  const int shell = lo;
+  const long long cnt = shell_count(shell);
+  const long long t = (long long)(B - block_base[shell]) * BLOCK + threadIdx.x;
+  double loss = 0.0;
+  if (t < cnt) {
+    int di, dj, dk;
+    shell_decode(shell, (int)t, di, dj, dk);
+    const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] &&
+                        dk <= S.hi[2];
+    const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
+                          dk == S.hi[2];
+    if (inside && boundary) {
+      const size_t cz = g.colsize;
+      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
+      const double *cs = col + (size_t)S.slot * 6 * cz;
+      const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
+      const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
+      if (cin_HI < max_coldensh) {
+        double vol_ph;
+        if (shell == 0) {
+          vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
+        } else {
+          const double path = sc_path(di, dj, dk) * sc.dr1;
+          const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
+          const double dist2 = xs * xs + ys * ys + zs * zs;
+          vol_ph = 4.0 * pi * dist2 * path;
+        }
+        double po;
+        if (ba.multi) {
+          const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+          po = photo_out_multi(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, nf);
+        } else {
+          po = photo_out_only(*bd, ss.photo_thick[0], ss.photo_thin[0], cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII,
+                              cout_HeII, S.nflux);
+        }
+        loss = po * sc.vol / vol_ph;
+      }
+    }
+  }
+  const double bs = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * blocks_total + B] = bs;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,7 +313,12 @@ k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__r
       cs[p + 5 * cz] = cout_HeII;
       const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
                             dk == S.hi[2];
-      if (boundary && cin_HI < max_coldensh) {
+      // The loss of a round that is certainly not a source's last only has to show that it exceeds the
+      // threshold of evolve_source.F90:136.  Every term is >= 0, so one wave in 16 of the boundary cells
+      // gives a lower bound (S.exact == 0; whole waves, or the other lanes would idle through the same
+      // code).  Rounds whose loss is kept are evaluated in full (k_loss_exact when the sample was not
+      // decisive).
+      if (boundary && cin_HI < max_coldensh && (S.exact || (((int)t >> 6) & 15) == 0)) {
         double po;
         if (ba.multi) {
           const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
@@ -286,15 +360,6 @@ k_col_to_grid(Grid g, SrcInfo S, const double *__restrict__ cs, double *__restri
   const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] && dk <= S.hi[2];
   const size_t p = shell_position(di, dj, dk);
   for (int c = 0; c < 3; c++) out[q + c * g.ncell] = inside ? cs[p + (size_t)(3 + c) * g.colsize] : 0.0;
-}
-
-// path length of cinterp for an offset, without the corner work (column_density.f90:194,269,341)
-__device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
-  const int ia = idel < 0 ? -idel : idel, ja = jdel < 0 ? -jdel : jdel, ka = kdel < 0 ? -kdel : kdel;
-  const double di = (double)idel, dj = (double)jdel, dk = (double)kdel;
-  if (ka >= ja && ka >= ia) return sqrt((di * di + dj * dj) / (dk * dk) + 1.0);
-  if (ja >= ia && ja >= ka) return sqrt((di * di + dk * dk) / (dj * dj) + 1.0);
-  return sqrt(1.0 + (dj * dj + dk * dk) / (di * di));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -623,6 +688,7 @@ struct c2r_ctx {
   double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
   int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr}; // tile lists of the rates launches (h: pinned)
   std::vector<unsigned char> tile_mark;
+  int *d_block_base = nullptr;     // device copy of block_base
   int blocks_total = 0;            // blocks of all shells 0..smax
   std::vector<int> block_base;     // first block of shell s in a partial-sum row
   double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
@@ -771,6 +837,8 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     c->block_base[s + 1] = c->block_base[s] + (int)((shell_count(s) + BLOCK - 1) / BLOCK);
   c->blocks_total = c->block_base[c->g.smax + 1];
   CR(hipMalloc(&c->d_loss_partial, sizeof(double) * (size_t)c->blocks_total * MAXB));
+  CR(hipMalloc(&c->d_block_base, sizeof(int) * c->block_base.size()));
+  CR(hipMemcpy(c->d_block_base, c->block_base.data(), sizeof(int) * c->block_base.size(), hipMemcpyHostToDevice));
   {
     const size_t ntiles = (size_t)((mesh[0] + 7) / 8) * ((mesh[1] + 7) / 8) * ((mesh[2] + 3) / 4);
     for (int k = 0; k < 2; k++) {
@@ -798,7 +866,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_stateT, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump};
+                  c->d_rates_own, c->d_stateT, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
@@ -1098,6 +1166,7 @@ struct SrcRun {
   int nbox = 0;
   double total_flux = 0, loss = 0;
   bool active = true;
+  bool exact = true;      // this round's photon loss is kept (last round for geometric reasons): evaluate it in full
   int smax_prev = -1;     // largest shell already swept
 };
 
@@ -1217,6 +1286,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           r.last_r[d] = std::min(SUBBOXSIZE * r.nbox, r.lastpos_r[d]);
           r.last_l[d] = std::max(-SUBBOXSIZE * r.nbox, r.lastpos_l[d]);
         }
+        // the while-test after this round fails whatever the loss when the box has reached the mesh in z
+        r.exact = !(r.last_r[2] < r.lastpos_r[2] && r.last_l[2] > r.lastpos_l[2]);
         SrcInfo &S = ba.s[ba.n];
         const int *p = &c->srcpos[3 * (size_t)(r.ns - 1)];
         S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
@@ -1224,7 +1295,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         S.nflux = c->normflux[r.ns - 1];
         for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][r.ns - 1];
         S.slot = slot0 + b;
-        S.pad = 0;
+        S.exact = r.exact ? 1 : 0;
         act_idx[ba.n] = b;
         ba.n++;
         s_lo = std::min(s_lo, r.smax_prev + 1);
@@ -1247,9 +1318,37 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * MAXB, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      // A sampled loss (a lower bound) that clears the threshold with a factor 2 to spare decides
+      // "continue" and is never looked at again; anything else is replaced by the full sum.
+      {
+        BatchArgs bx;
+        bx.n = 0;
+        bx.multi = ba.multi;
+        int redo[MAXB];
+        for (int a = 0; a < ba.n; a++) {
+          SrcRun &r = run[act_idx[a]];
+          r.loss = c->h_loss[a];
+          if (!r.exact && !(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) {
+            bx.s[bx.n] = ba.s[a];
+            bx.s[bx.n].exact = 1;
+            redo[bx.n++] = a;
+          }
+        }
+        if (bx.n > 0) {
+          const int first = c->block_base[s_lo], count = c->block_base[s_hi + 1] - first;
+          hipLaunchKernelGGL(k_loss_exact, dim3(count, bx.n), dim3(BLOCK), 0, c->stream, g, bx, s_lo, s_hi, sc, c->d_col,
+                             c->d_bands, ss, c->d_block_base, c->d_loss_partial, c->blocks_total);
+          hipLaunchKernelGGL(k_loss_finish, dim3(bx.n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, c->blocks_total, first,
+                             count, c->d_loss_acc);
+          c->tm.sweep_launches += 2;
+          HIPCHK(c, hipGetLastError());
+          HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * MAXB, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          for (int j = 0; j < bx.n; j++) run[act_idx[redo[j]]].loss = c->h_loss[j];
+        }
+      }
       for (int a = 0; a < ba.n; a++) {
         SrcRun &r = run[act_idx[a]];
-        r.loss = c->h_loss[a];
         // cells traced in this round: the part of the new box not in the previous one
         long long vol_new = 1, vol_old = 1;
         for (int d = 0; d < 3; d++) {
@@ -1277,7 +1376,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       S.nflux = c->normflux[run[b].ns - 1];
       for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][run[b].ns - 1];
       S.slot = slot0 + b;
-      S.pad = 0;
+      S.exact = 1;
     }
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[set], 0));
     if (c->timing) HIPCHK(c, hipEventRecord(e_r0, c->stream2));
