@@ -10,7 +10,7 @@ import sys
 
 
 def kname(n):
-    for k in ("k_rates", "k_chemistry", "k_sweep_shell", "k_loss_finish", "k_transpose_ij"):
+    for k in ("k_rates", "k_chemistry", "k_sweep_shell", "k_loss_finish", "k_loss_exact", "k_transpose_ij"):
         if k in n:
             return k
     return None
@@ -21,7 +21,7 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.defaultdict(lambda: collections.defaultdict(int))
     for d in dirs:
-        for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for f in glob.glob(d + "/*counter_collection.csv") + glob.glob(d + "/*/*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 k = kname(r["Kernel_Name"])
                 if k:
