@@ -29,6 +29,7 @@
 #define C2R_MATH_EXP(x) exp(x)
 #define C2R_MATH_LOG10(x) log10(x)
 #define C2R_MATH_LOG10P(x) log10(x)
+#define C2R_MATH_LOG10N(x) log10(x)
 #define C2R_MATH_POW(x, y) pow(x, y)
 #endif
 
@@ -399,7 +400,7 @@ C2R_HD TauPos tau_table_position(double tau) {
 #ifdef C2R_ABL_LOG // timing-only ablation (wrong results): what does log10 cost?
   double lt = dmax(1.0e-20, tau) * 1.0e-3 - 3.0;
 #else
-  double lt = C2R_MATH_LOG10P(dmax(1.0e-20, tau));
+  double lt = C2R_MATH_LOG10N(dmax(1.0e-20, tau)); // positive, normal and finite by construction
 #endif
   // (lt - minlogtau)/dlogtau, correctly rounded through the constant's reciprocal (div_recip);
   // the numerator lies in [0, 24.5], dlogtau = 0x1.89374bc6a7efap-7
@@ -407,7 +408,8 @@ C2R_HD TauPos tau_table_position(double tau) {
   const double rdl = 1.0 / dlogtau;
   const double q0 = num * rdl;
   const double quo = __builtin_fma(__builtin_fma(-dlogtau, q0, num), rdl, q0);
-  double odpos = dmin((double)NTAU, dmax(0.0, 1.0 + quo));
+  // max(0, .) of the reference (:299) cannot bind: lt >= log10(1e-20) makes 1 + quo >= 1 - 1e-12
+  double odpos = dmin((double)NTAU, 1.0 + quo);
   TauPos p;
   p.ipos = (int)odpos;
   p.residual = odpos - (double)p.ipos;

@@ -132,10 +132,11 @@ C2R_MHD double log10_(double x) {
 // temperatures): the same operations as log10_/log_core, with the 64-bit integer bookkeeping done
 // on the high 32-bit word (every constant involved has a zero low word, so this is exact) and
 // without the out-of-domain branch.  Bit-identical to log10_ (tests/test_math_host.py).
-C2R_MHD double log10_pos(double x) {
+// log10_norm: the caller guarantees a positive, normal, finite argument (tau_table_position passes
+// max(1e-20, tau)); log10_pos adds the check and falls back to log10_.
+C2R_MHD double log10_norm(double x) {
   const uint64_t ix = asuint64(x);
   const uint32_t hi = (uint32_t)(ix >> 32), lo = (uint32_t)ix;
-  if (hi - 0x00100000u >= 0x7FE00000u) return log10_(x); // zero, subnormal, negative, inf, nan
   const double ivln10 = asdouble(0x3FDBCB7B1526E50EULL);
   const double log10_2hi = asdouble(0x3FD34413509F6000ULL);
   const double log10_2lo = asdouble(0x3D59FEF311F12B36ULL);
@@ -174,6 +175,11 @@ C2R_MHD double log10_pos(double x) {
   }
   const double zz = y * log10_2lo + ivln10 * lg;
   return zz + y * log10_2hi;
+}
+C2R_MHD double log10_pos(double x) {
+  const uint32_t hi = (uint32_t)(asuint64(x) >> 32);
+  if (hi - 0x00100000u >= 0x7FE00000u) return log10_(x); // zero, subnormal, negative, inf, nan
+  return log10_norm(x);
 }
 
 // ---- exp: __exp_fma ----------------------------------------------------------------------------
@@ -315,4 +321,5 @@ C2R_MHD double pow_(double x, double y) {
 #define C2R_MATH_EXP(x) ::c2r::gm::exp_(x)
 #define C2R_MATH_LOG10(x) ::c2r::gm::log10_(x)
 #define C2R_MATH_LOG10P(x) ::c2r::gm::log10_pos(x)
+#define C2R_MATH_LOG10N(x) ::c2r::gm::log10_norm(x)
 #define C2R_MATH_POW(x, y) ::c2r::gm::pow_(x, y)
