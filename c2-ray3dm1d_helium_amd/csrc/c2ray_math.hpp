@@ -51,38 +51,42 @@ C2R_MHD double asdouble(uint64_t u) { return __builtin_bit_cast(double, u); }
 C2R_MHD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ---- log: __log_fma ---------------------------------------------------------------------------
+// the branch of __log_fma for 1 - 0x1p-4 <= x < 1 + 0x1.09p-4 (precondition)
+C2R_MHD double log_near1(double x) {
+  const double *B = GMT(log_hdr) + 7;
+  // (glibc returns 0 for x == 1 up front; with r == 0 every term below is +0 in round-to-nearest,
+  // so the shortcut changes nothing and is left out)
+  const double r = x - 1.0;
+  const double u1 = fma_(r, B[2], B[1]);
+  const double u2 = fma_(r, B[5], B[4]);
+  const double r2 = r * r;
+  const double u3 = fma_(r, B[8], B[7]);
+  const double v1 = fma_(r2, B[3], u1);
+  const double v2 = fma_(r2, B[6], u2);
+  const double r3 = r * r2;
+  double v3 = fma_(r2, B[9], u3);
+  v3 = fma_(r3, B[10], v3);
+  const double w2 = fma_(v3, r3, v2);
+  const double P = fma_(w2, r3, v1);
+  const double t = fma_(r, 0x1p27, r);
+  const double rhi = fma_(-0x1p27, r, t);
+  const double rhi2 = rhi * rhi;
+  const double rlo = r - rhi;
+  const double hi = fma_(rhi2, B[0], r);
+  const double lo = fma_(rhi2, B[0], r - hi);
+  const double lo2 = fma_(B[0] * rlo, r + rhi, lo);
+  const double y = fma_(P, r3, lo2);
+  return hi + y;
+}
 // precondition: x finite, positive, normal
 C2R_MHD double log_core(double x) {
   const double *H = GMT(log_hdr);
   const double Ln2hi = H[0], Ln2lo = H[1];
-  const double *A = H + 2, *B = H + 7;
+  const double *A = H + 2;
   const uint64_t ix = asuint64(x);
   const uint64_t LO = 0x3FEE000000000000ULL; // asuint64(1.0 - 0x1p-4)
   const uint64_t HI = 0x3FF1090000000000ULL; // asuint64(1.0 + 0x1.09p-4)
-  if (ix - LO < HI - LO) {
-    if (ix == 0x3FF0000000000000ULL) return 0.0;
-    const double r = x - 1.0;
-    const double u1 = fma_(r, B[2], B[1]);
-    const double u2 = fma_(r, B[5], B[4]);
-    const double r2 = r * r;
-    const double u3 = fma_(r, B[8], B[7]);
-    const double v1 = fma_(r2, B[3], u1);
-    const double v2 = fma_(r2, B[6], u2);
-    const double r3 = r * r2;
-    double v3 = fma_(r2, B[9], u3);
-    v3 = fma_(r3, B[10], v3);
-    const double w2 = fma_(v3, r3, v2);
-    const double P = fma_(w2, r3, v1);
-    const double t = fma_(r, 0x1p27, r);
-    const double rhi = fma_(-0x1p27, r, t);
-    const double rhi2 = rhi * rhi;
-    const double rlo = r - rhi;
-    const double hi = fma_(rhi2, B[0], r);
-    const double lo = fma_(rhi2, B[0], r - hi);
-    const double lo2 = fma_(B[0] * rlo, r + rhi, lo);
-    const double y = fma_(P, r3, lo2);
-    return hi + y;
-  }
+  if (ix - LO < HI - LO) return log_near1(x);
   const uint64_t tmp = ix - 0x3FE6000000000000ULL; // OFF
   const int i = (int)((tmp >> 45) & 127);
   const int k = (int)((int64_t)tmp >> 52);
@@ -147,8 +151,8 @@ C2R_MHD double log10_norm(double x) {
   double lg;
   const double *H = GMT(log_hdr);
   if (hx - 0x3FEE0000u < 0x00030900u) {
-    // |x' - 1| small: the polynomial path of log_core
-    lg = log_core(asdouble(((uint64_t)hx << 32) | lo));
+    // |x' - 1| small: the polynomial path of __log_fma
+    lg = log_near1(asdouble(((uint64_t)hx << 32) | lo));
   } else {
     const double Ln2hi = H[0], Ln2lo = H[1];
     const double *A = H + 2;
