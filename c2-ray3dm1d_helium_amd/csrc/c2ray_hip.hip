@@ -448,15 +448,18 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
 
 // ---------------------------------------------------------------------------------------------
 // evolve0D_global + do_chemistry (files_for_3D/evolve_point.F90:325-440, :444-646), one cell per lane.
+#ifndef C2R_CHEM_BLOCK
+#define C2R_CHEM_BLOCK 64
+#endif
 template <bool HEAT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(C2R_CHEM_BLOCK)
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
             const float *__restrict__ clumping_grid) {
   const size_t nc = g.ncell;
-  const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t q = (size_t)blockIdx.x * C2R_CHEM_BLOCK + threadIdx.x;
   int notconv = 0;
   if (q < nc) {
     // clumping_point for type_of_clumping = 5 (evolve_point.F90:483-484; REAL(4) grid)
@@ -1554,15 +1557,15 @@ extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
   HIPCHK(c, hipSetDevice(c->device));
   const Grid g = c->g;
   const StepScalars sc = scalars(c);
-  const int nblk = (int)((g.ncell + BLOCK - 1) / BLOCK);
+  const int nblk = (int)((g.ncell + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
   HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   if (c->isothermal)
-    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
+    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr);
   else
-    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
+    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr);
   HIPCHK(c, hipGetLastError());
