@@ -53,6 +53,11 @@ module evolve
   use evolve_data, only: phih_grid, phihe_grid, phiheat
   use evolve_data, only: xh_av, xhe_av, xh_intermed, xhe_intermed
   use evolve_data, only: photon_loss_all, hip_ctx
+  use evolve_source, only: sum_nbox, sum_nbox_all
+#ifdef C2RAY_REFERENCE_DO_GRID
+  ! the reference's own master_slave.F90, unmodified: its do_source calls land in our evolve_source
+  use master_slave_processing, only: do_grid
+#endif
   use, intrinsic :: iso_c_binding
   use c2ray_hip
 
@@ -63,10 +68,6 @@ module evolve
   private
 
   public :: evolve3D
-
-  !> sum of all nboxes (the reference keeps these in module evolve_source)
-  integer,public :: sum_nbox
-  integer,public :: sum_nbox_all
 
   logical :: tables_uploaded = .false.
   !> number of H0, H+, He0, He+, He++ at the start of the time step (state_before)
@@ -169,7 +170,7 @@ contains
        LLS_loss = 0.0
 
        if (NumSrc > 0) then
-          call pass_all_sources ()
+          call pass_all_sources (niter,dt)
 
           if (rank == 0) then
              write(logf,*) "Average number of subboxes: ", real(sum_nbox_all)/real(NumSrc)
@@ -247,7 +248,10 @@ contains
 
   !----------------------------------------------------------------------------
 
-  subroutine pass_all_sources ()
+  subroutine pass_all_sources (niter,dt)
+
+    integer,intent(in) :: niter
+    real(kind=dp),intent(in) :: dt
 
     integer(c_int) :: nbox
     real(kind=dp) :: tail(NumFreqBnd)
@@ -256,7 +260,11 @@ contains
 
     ! static distribution of the sources over the ranks: ns = 1+rank, NumSrc, npr
     ! (do_grid_static, master_slave.F90:74-96)
+#ifdef C2RAY_REFERENCE_DO_GRID
+    call do_grid (dt,niter)
+#else
     call check (c2r_pass_sources (hip_ctx, int(1+rank,c_int), int(npr,c_int)), "c2r_pass_sources")
+#endif
 
 #ifdef MPI
     ! mpi_accumulate_grid_quantities (evolve.F90:505-548) through host staging buffers

@@ -21,19 +21,23 @@ sys.path.insert(0, str(ROOT / "oracle"))
 @pytest.mark.parametrize("iso,pl,sources", [
     (False, "lls", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),   # use_LLS = .true. build
     (False, False, [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
+    # C2Ray_3D_hip_dogrid: the reference's own master_slave.F90 (unmodified) deals out the sources and calls
+    # do_source of the product's module evolve_source -- the do_source call surface, one source per call
+    (False, "dogrid", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     (True, False, [(8, 8, 8, 1e55)]),
     # the -DPL -DQUASARS build (the flags of the reference's production targets, Makefile:185-186,207-208)
     (False, True, [(8, 8, 8, 1e55, 3e54, 0.0), (2, 15, 4, 0.0, 2e54, 4e54), (16, 1, 9, 2e54, 0.0, 1e54)]),
 ])
 def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, sources):
     import refrun
-    lls, pl = pl == "lls", pl is True
-    ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, "hip", pl=pl, lls=lls)
+    lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
+    which_hip = "hip_dogrid" if dogrid else "hip"
+    ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "")
     r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl, lls=lls)
-    r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="hip", name=f"dropin_hip_{tag}", pl=pl, lls=lls)
+    r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls)
     files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
     assert len(files) >= 15, files
     for f in files:
