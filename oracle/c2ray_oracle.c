@@ -963,3 +963,64 @@ int orc_evolve3d(const orc_tables *tb, const orc_step *st, orc_state *s, double 
   s->niter = niter;
   return niter;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * radiation_tables.f90:172-422 spec_integration for one SED, from what spectrum_parms /
+ * setup_scalingfactors / romberg_initialisation / normalize_seds leave behind (orc_sed_setup).
+ * Integrands: fill_photo_integrands :462-536, fill_heating_integrands_* :540-783; integration:
+ * Vector_Romberg, romberg.f90:158-188 (serial sum over the 513 frequencies, weight delta_freq).
+ * Tables are (0:NumTau, ncol), tau index fastest, like the reference's.
+ */
+static double sed_photo_integrand(const orc_sed_setup *S, double freq, double csfd, double tau, int thin) {
+  /* :471 the cut-off that avoids underflow of exp(-tau*...) ; 700.0 is a REAL(4) literal (exact) */
+  if (!(tau * csfd < 700.0)) return 0.0;
+  if (S->sed == 0) {
+    if (!(freq * S->h_over_kT < 700.0)) return 0.0; /* :474 */
+    double t = 4.0 * S->pi * S->R_star2 * S->two_pi_over_c_square * freq * freq;
+    if (thin) t = t * csfd;
+    t = t * exp(-tau * csfd);
+    return t / (exp(freq * S->h_over_kT) - 1.0);
+  }
+  double t = S->pl_scaling * pow(freq, -S->pl_index); /* :491-510 */
+  if (thin) t = t * csfd;
+  return t * exp(-tau * csfd);
+}
+
+void orc_build_tables(const orc_sed_setup *S, int heat, double *photo_thick, double *photo_thin,
+                      double *heat_thick, double *heat_thin) {
+  const int nf = S->nfreq, nt = ORC_NTAU + 1;
+  double *freq = malloc((size_t)(nf + 1) * sizeof(double)), *csfd = malloc((size_t)(nf + 1) * sizeof(double));
+  for (int b = 1; b <= NB1 + NB2 + NB3; b++) {
+    const double fmin = S->freq_min[b - 1], df = S->delta_freq[b - 1];
+    for (int i = 0; i <= nf; i++) { /* set_frequency_array :438, set_cross_section_freq_dependence :449 */
+      freq[i] = fmin + df * (double)(float)i;
+      csfd[i] = pow(freq[i] / fmin, -S->xsec_index[b - 1]);
+    }
+    /* heating columns of this band and their threshold frequencies (:300-310, :343-390) */
+    int hcol[3], nh;
+    const double f0[3] = {S->ion_freq_HI, S->ion_freq_HeI, S->ion_freq_HeII};
+    if (b <= NB1) { nh = 1; hcol[0] = 1; }
+    else if (b <= NB1 + NB2) { nh = 2; hcol[0] = b * 2 - NB1 - 1; hcol[1] = b * 2 - NB1; }
+    else { nh = 3; hcol[0] = b * 3 - NB2 - NB1 * 2 - 2; hcol[1] = hcol[0] + 1; hcol[2] = hcol[0] + 2; }
+    for (int it = 0; it < nt; it++) {
+      const double tau = S->tau[it];
+      for (int thin = 0; thin < 2; thin++) {
+        double itg = 0.0, itgh[3] = {0.0, 0.0, 0.0};
+        for (int x = 0; x <= nf; x++) {
+          const double f = sed_photo_integrand(S, freq[x], csfd[x], tau, thin);
+          itg = itg + f * df * S->romw[x];
+          if (heat)
+            for (int k = 0; k < nh; k++) {
+              const double fh = S->hplanck * (freq[x] - f0[k]) * f;
+              itgh[k] = itgh[k] + fh * df * S->romw[x];
+            }
+        }
+        (thin ? photo_thin : photo_thick)[(size_t)(b - 1) * nt + it] = itg;
+        if (heat)
+          for (int k = 0; k < nh; k++) (thin ? heat_thin : heat_thick)[(size_t)(hcol[k] - 1) * nt + it] = itgh[k];
+      }
+    }
+  }
+  free(freq);
+  free(csfd);
+}

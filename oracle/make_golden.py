@@ -57,6 +57,8 @@ def cooling_tables():
     return np.concatenate(cols), float(temp[0]), float(temp[1]) - float(temp[0])
 
 
+SED_SETUP_KEYS = ["freq_min", "delta_freq", "pl_index_HI", "pl_index_HeI", "pl_index_HeII", "tau", "romw9", "sed_setup",
+                  "pl_setup", "qpl_setup", "consts", "pl_limits", "qpl_limits"]
 KEEP_OUT = ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av", "photon_loss_all",
             "sum_nbox_all", "reccoef", "coldensh_out", "coldenshe_out"]
 
@@ -158,6 +160,9 @@ def main():
                 a[~used] = 0.0
                 sed[f"{pre}{kind}_{tt}"] = a.reshape(-1)
     np.savez_compressed(GOLD / "rad_tables_pl_qpl.npz", **sed)
+    # what spec_integration starts from (band set-up, Romberg weights, normalised SEDs): the inputs of the
+    # table builders (orc_build_tables, c2r_build_tables)
+    np.savez_compressed(GOLD / "sed_setup.npz", **{k: tb[k] for k in SED_SETUP_KEYS})
     for d in refrun.REFDIR.glob("golden_*"):
         shutil.rmtree(d)  # run directories are scratch
     for p in sorted(list(GOLD.glob("*.npz")) + list(PKGDATA.glob("*.npz"))):

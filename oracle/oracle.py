@@ -302,3 +302,41 @@ def constants():
     buf = (C.c_double * 64)()
     n = lib().orc_constants(buf, 64)
     return np.array(buf[:n])
+
+
+class CSedSetup(C.Structure):
+    _fields_ = [("nfreq", C.c_int), ("sed", C.c_int), ("freq_min", _dp), ("delta_freq", _dp), ("xsec_index", _dp),
+                ("tau", _dp), ("romw", _dp), ("R_star2", C.c_double), ("h_over_kT", C.c_double),
+                ("two_pi_over_c_square", C.c_double), ("hplanck", C.c_double), ("pi", C.c_double),
+                ("ion_freq_HI", C.c_double), ("ion_freq_HeI", C.c_double), ("ion_freq_HeII", C.c_double),
+                ("pl_scaling", C.c_double), ("pl_index", C.c_double)]
+
+
+def xsec_index(d):
+    """The index spec_integration passes per band: HI's for band 1, HeI's for 2..27, HeII's for 28..47
+    (radiation_tables.f90:278,315,349)."""
+    b = np.arange(1, 48)
+    return np.where(b <= 1, d["pl_index_HI"], np.where(b <= 27, d["pl_index_HeI"], d["pl_index_HeII"])).astype(np.float64)
+
+
+def build_tables(d, sed=0, heat=True):
+    """spec_integration for one SED from a set-up dictionary (keys as dumped by the tap: freq_min,
+    delta_freq, pl_index_*, tau, romw9, sed_setup, consts, [pl_setup | qpl_setup])."""
+    lib_ = lib()
+    lib_.orc_build_tables.restype = None
+    lib_.orc_build_tables.argtypes = [C.POINTER(CSedSetup), C.c_int, _dp, _dp, _dp, _dp]
+    keep = [np.ascontiguousarray(d[k], dtype=np.float64) for k in ("freq_min", "delta_freq", "tau", "romw9")]
+    keep.append(np.ascontiguousarray(xsec_index(d)))
+    s = CSedSetup()
+    s.nfreq, s.sed = 512, int(sed)
+    s.freq_min, s.delta_freq, s.tau, s.romw, s.xsec_index = (_p(a) for a in keep)
+    s.R_star2, s.h_over_kT, s.two_pi_over_c_square = (float(x) for x in d["sed_setup"])
+    c = d["consts"]
+    s.pi, s.hplanck = float(c[0]), float(c[5])
+    s.ion_freq_HI, s.ion_freq_HeI, s.ion_freq_HeII = float(c[22]), float(c[23]), float(c[24])
+    if sed:
+        s.pl_scaling, s.pl_index = (float(x) for x in d["pl_setup" if sed == 1 else "qpl_setup"])
+    nt = NTAU + 1
+    out = [np.zeros(47 * nt), np.zeros(47 * nt), np.zeros(113 * nt), np.zeros(113 * nt)]
+    lib_.orc_build_tables(C.byref(s), int(bool(heat)), *[_p(a) for a in out])
+    return dict(zip(("photo_thick", "photo_thin", "heat_thick", "heat_thin"), out))

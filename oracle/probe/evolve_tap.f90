@@ -165,7 +165,17 @@ contains
          cross_section_HeII_powerlaw_index
     use radiation_tables, only: bb_photo_thick_table, bb_photo_thin_table, &
          bb_heat_thick_table, bb_heat_thin_table, bb_FreqBnd_UpperLimit, minlogtau, dlogtau
-    use radiation_sed_parameters, only: T_eff, R_star, L_star
+    use radiation_sed_parameters, only: T_eff, R_star, L_star, R_star2, h_over_kT
+    use radiation_tables, only: tau
+    use radiation_sizes, only: NumFreq
+    use romberg, only: romw
+    use cgsconstants, only: two_pi_over_c_square
+#ifdef PL
+    use radiation_sed_parameters, only: pl_scaling, pl_index
+#endif
+#ifdef QUASARS
+    use radiation_sed_parameters, only: qpl_scaling, qpl_index
+#endif
 #ifdef PL
     use radiation_tables, only: pl_photo_thick_table, pl_photo_thin_table, pl_heat_thick_table, &
          pl_heat_thin_table, pl_FreqBnd_UpperLimit, pl_FreqBnd_LowerLimit
@@ -228,6 +238,16 @@ contains
        call put_d(u, "f2heat_HeI", f2heat_HeI, size(f2heat_HeI))
        call put_d(u, "f2heat_HeII", f2heat_HeII, size(f2heat_HeII))
     endif
+    ! what spec_integration (radiation_tables.f90:172-422) starts from, besides the band vectors above
+    call put_d(u, "sed_setup", (/R_star2, h_over_kT, two_pi_over_c_square/), 3)
+    call put_d(u, "tau", tau, size(tau))
+    call put_d(u, "romw9", romw(0:NumFreq,9), NumFreq+1)
+#ifdef PL
+    call put_d(u, "pl_setup", (/pl_scaling, pl_index/), 2)
+#endif
+#ifdef QUASARS
+    call put_d(u, "qpl_setup", (/qpl_scaling, qpl_index/), 2)
+#endif
     call put_d(u, "photo_thick", bb_photo_thick_table, size(bb_photo_thick_table))
     call put_d(u, "photo_thin", bb_photo_thin_table, size(bb_photo_thin_table))
     if (allocated(bb_heat_thick_table)) then
