@@ -27,6 +27,15 @@ class Timing(C.Structure):
                 ("cells_swept", C.c_longlong)]
 
 
+class SedSetup(C.Structure):
+    """struct c2r_sed_setup (include/c2ray_hip.h)."""
+    _fields_ = [("nfreq", C.c_int), ("sed", C.c_int), ("freq_min", _dp), ("delta_freq", _dp), ("xsec_index", _dp),
+                ("tau", _dp), ("romw", _dp), ("R_star2", C.c_double), ("h_over_kT", C.c_double),
+                ("two_pi_over_c_square", C.c_double), ("hplanck", C.c_double), ("pi", C.c_double),
+                ("ion_freq_HI", C.c_double), ("ion_freq_HeI", C.c_double), ("ion_freq_HeII", C.c_double),
+                ("pl_scaling", C.c_double), ("pl_index", C.c_double)]
+
+
 # every symbol include/c2ray_hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "c2r_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _ip]),
@@ -40,6 +49,8 @@ SYMBOLS = {
     "c2r_set_sources": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double]),
     "c2r_set_sed_tables": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int]),
     "c2r_set_sources_sed": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double]),
+    "c2r_build_tables": (C.c_int, [C.c_void_p, C.POINTER(SedSetup), C.c_int]),
+    "c2r_download_tables": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]),
     "c2r_set_lls": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _fp]),
     "c2r_set_clumping_grid": (C.c_int, [C.c_void_p, _fp]),
     "c2r_upload_state": (C.c_int, [C.c_void_p, _dp, _dp, _fp]),

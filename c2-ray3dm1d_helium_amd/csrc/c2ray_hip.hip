@@ -567,6 +567,60 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
 }
 
 // ---------------------------------------------------------------------------------------------
+// spec_integration (radiation_tables.f90:172-422) for one SED: every entry of the photo and heating
+// tables is a 513-point Romberg-weighted sum over frequency of an integrand that holds one exp(-tau*s(nu)).
+// One thread = one (tau, band, thick|thin): it walks the frequencies in order (Vector_Romberg is a serial
+// sum, romberg.f90:180-186) and carries the photo sum and the up-to-three heating sums of the band.
+// Per-frequency factors that do not depend on tau (SED shape, Planck denominator, h(nu - nu_ion)) come
+// from the host, computed with the same bit-exact exp/pow (build_sed_vectors below).
+// vec layout per band b, frequency x (index b*513 + x): csfd, A (numerator prefix), D (denominator),
+// H0, H1, H2 (heating factors) -- six arrays of 47*513.  out: device table layout, pitch NTAUP.
+constexpr int SEDV = NFREQ * 513;
+__global__ void __launch_bounds__(BLOCK)
+k_build_tables(const double *__restrict__ vec, const double *__restrict__ tau_tab, const double *__restrict__ romw,
+               const double *__restrict__ delta_freq, int heat, double *__restrict__ photo_thick,
+               double *__restrict__ photo_thin, double *__restrict__ heat_thick, double *__restrict__ heat_thin) {
+  const int it = blockIdx.x * BLOCK + threadIdx.x;
+  const int b = blockIdx.y >> 1, thin = blockIdx.y & 1; // band (0-based), table kind
+  if (it > NTAU) return;
+  const double tau = tau_tab[it], df = delta_freq[b];
+  const double *csfd = vec + (size_t)b * 513, *A = csfd + SEDV, *D = A + SEDV;
+  const double *H0 = D + SEDV, *H1 = H0 + SEDV, *H2 = H1 + SEDV;
+  const int nh = b < NB1 ? 1 : (b < NB1 + NB2 ? 2 : 3);
+  double itg = 0.0, h0 = 0.0, h1 = 0.0, h2 = 0.0;
+  for (int x = 0; x <= 512; x++) {
+    const double s_ = csfd[x];
+    double f = 0.0;
+    if (tau * s_ < 700.0) { // :471
+      double t = A[x];
+      if (thin) t = t * s_;
+      t = t * C2R_MATH_EXP(-tau * s_);
+      f = t / D[x];
+    }
+    const double w = romw[x];
+    itg = itg + f * df * w;
+    if (heat) {
+      h0 = h0 + (H0[x] * f) * df * w;
+      if (nh > 1) h1 = h1 + (H1[x] * f) * df * w;
+      if (nh > 2) h2 = h2 + (H2[x] * f) * df * w;
+    }
+  }
+  double *pt = (thin ? photo_thin : photo_thick) + (size_t)b * NTAUP;
+  pt[it] = itg;
+  if (it == NTAU) pt[NTAU + 1] = itg; // the duplicated last row (read_table)
+  if (heat) {
+    // heating columns of the band (radiation_tables.f90:300-310, 343-390), 0-based
+    const int c0 = b < NB1 ? 0 : (b < NB1 + NB2 ? 2 * (b + 1) - NB1 - 2 : 3 * (b + 1) - NB2 - 2 * NB1 - 3);
+    double *ht = (thin ? heat_thin : heat_thick) + (size_t)c0 * NTAUP;
+    const double hv[3] = {h0, h1, h2};
+    for (int k = 0; k < nh; k++) {
+      ht[(size_t)k * NTAUP + it] = hv[k];
+      if (it == NTAU) ht[(size_t)k * NTAUP + NTAU + 1] = hv[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // photonstatistics.f90: the grid sums of state_before/state_after (:117-144, :208-234) and of
 // total_rates (:150-203).  Fixed launch shape (STAT_BLOCKS x 256, grid-stride, block tree, then one
 // finishing block) => the same bits on every run; the order differs from the reference's serial
@@ -652,7 +706,7 @@ struct c2r_ctx {
 
   double *d_photo_thick = nullptr, *d_photo_thin = nullptr, *d_heat_thick = nullptr, *d_heat_thin = nullptr;
   BandData *d_bands = nullptr;
-  bool have_tables = false, have_heat_tables = false;
+  bool have_tables = false, have_heat_tables = false, have_bands = false, have_fvec = false;
   int bb_upper = 0;
   double *d_cool = nullptr;
   bool have_cool = false;
@@ -673,7 +727,7 @@ struct c2r_ctx {
   // -DPL / -DQUASARS: power-law (0) and quasar-like (1) SEDs
   double *d_sed_tab[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   int sed_lo[2] = {0, 0}, sed_hi[2] = {0, 0}; // 0-based [lo, hi)
-  bool have_sed[2] = {false, false}, have_sed_heat[2] = {false, false};
+  bool have_sed[2] = {false, false}, have_sed_heat[2] = {false, false}, have_sed_limits[2] = {false, false};
   std::vector<double> normflux_sed[2];
   double s_star_sed[2] = {0, 0};
 
@@ -911,33 +965,43 @@ extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const doubl
                               const double *sigma_HeI, const double *sigma_HeII, const double *const fvec[12],
                               int bb_upper) {
   if (!c) return 1;
-  if (!photo_thick || !photo_thin || !sigma_HI || !sigma_HeI || !sigma_HeII)
-    return fail(c, "c2r_set_tables: photo tables and cross sections are required");
+  if (!sigma_HI || !sigma_HeI || !sigma_HeII) return fail(c, "c2r_set_tables: the cross sections are required");
+  if ((photo_thick == nullptr) != (photo_thin == nullptr) || (heat_thick == nullptr) != (heat_thin == nullptr))
+    return fail(c, "c2r_set_tables: thick and thin tables come in pairs");
   if (bb_upper < 1 || bb_upper > NFREQ) return fail(c, "c2r_set_tables: bb_upper %d not in [1,%d]", bb_upper, NFREQ);
   HIPCHK(c, hipSetDevice(c->device));
-  if (upload_table(c, photo_thick, NFREQ, &c->d_photo_thick)) return 1;
-  if (upload_table(c, photo_thin, NFREQ, &c->d_photo_thin)) return 1;
+  // without tables this call only sets the band vectors; c2r_build_tables makes the tables on the device
+  c->have_tables = false;
+  if (photo_thick) {
+    if (upload_table(c, photo_thick, NFREQ, &c->d_photo_thick)) return 1;
+    if (upload_table(c, photo_thin, NFREQ, &c->d_photo_thin)) return 1;
+    c->have_tables = true;
+  }
   c->have_heat_tables = false;
+  c->have_fvec = false;
   BandData bd;
   std::memset(&bd, 0, sizeof bd);
   std::memcpy(bd.sigma_HI, sigma_HI, sizeof bd.sigma_HI);
   std::memcpy(bd.sigma_HeI, sigma_HeI, sizeof bd.sigma_HeI);
   std::memcpy(bd.sigma_HeII, sigma_HeII, sizeof bd.sigma_HeII);
   bd.bb_upper = bb_upper;
-  if (heat_thick && heat_thin) {
-    if (!fvec) return fail(c, "c2r_set_tables: heat tables given without the secondary-ionisation vectors");
+  if (heat_thick && !fvec) return fail(c, "c2r_set_tables: heat tables given without the secondary-ionisation vectors");
+  if (fvec) {
     for (int i = 0; i < 12; i++)
       if (!fvec[i]) return fail(c, "c2r_set_tables: fvec[%d] is NULL", i);
-    if (upload_table(c, heat_thick, NHEAT, &c->d_heat_thick)) return 1;
-    if (upload_table(c, heat_thin, NHEAT, &c->d_heat_thin)) return 1;
+    if (heat_thick) {
+      if (upload_table(c, heat_thick, NHEAT, &c->d_heat_thick)) return 1;
+      if (upload_table(c, heat_thin, NHEAT, &c->d_heat_thin)) return 1;
+    }
     double *dst[12] = {bd.f1ion_HI, bd.f1ion_HeI, bd.f1ion_HeII, bd.f2ion_HI, bd.f2ion_HeI, bd.f2ion_HeII,
                        bd.f1heat_HI, bd.f1heat_HeI, bd.f1heat_HeII, bd.f2heat_HI, bd.f2heat_HeI, bd.f2heat_HeII};
     for (int i = 0; i < 12; i++) std::memcpy(dst[i], fvec[i], sizeof(double) * (NFREQ - 1));
-    c->have_heat_tables = true;
+    c->have_fvec = true;
+    c->have_heat_tables = heat_thick != nullptr;
   }
   HIPCHK(c, hipMemcpy(c->d_bands, &bd, sizeof bd, hipMemcpyHostToDevice));
   c->bb_upper = bb_upper;
-  c->have_tables = true;
+  c->have_bands = true;
   return 0;
 }
 
@@ -992,14 +1056,19 @@ extern "C" int c2r_set_sed_tables(c2r_ctx *c, int sed, const double *photo_thick
                                   const double *heat_thick, const double *heat_thin, int lower, int upper) {
   if (!c) return 1;
   if (sed < 1 || sed > 2) return fail(c, "c2r_set_sed_tables: sed = %d, expected 1 (power law) or 2 (quasar)", sed);
-  if (!photo_thick || !photo_thin) return fail(c, "c2r_set_sed_tables: photo tables are required");
   if (lower < 1 || upper > NFREQ || lower > upper)
     return fail(c, "c2r_set_sed_tables: band range %d..%d not inside 1..%d", lower, upper, NFREQ);
   HIPCHK(c, hipSetDevice(c->device));
   const int k = sed - 1;
+  c->have_sed[k] = false;
+  c->have_sed_heat[k] = false;
+  c->sed_lo[k] = lower - 1;
+  c->sed_hi[k] = upper;
+  c->have_sed_limits[k] = true;
+  if (!photo_thick && !photo_thin) return 0; // band range only: c2r_build_tables makes the tables
+  if (!photo_thick || !photo_thin) return fail(c, "c2r_set_sed_tables: thick and thin tables come in pairs");
   if (upload_table(c, photo_thick, NFREQ, &c->d_sed_tab[k][0])) return 1;
   if (upload_table(c, photo_thin, NFREQ, &c->d_sed_tab[k][1])) return 1;
-  c->have_sed_heat[k] = false;
   if (heat_thick && heat_thin) {
     if (upload_table(c, heat_thick, NHEAT, &c->d_sed_tab[k][2])) return 1;
     if (upload_table(c, heat_thin, NHEAT, &c->d_sed_tab[k][3])) return 1;
@@ -1019,6 +1088,104 @@ extern "C" int c2r_set_sources_sed(c2r_ctx *c, int sed, const double *normflux, 
   if (!c->have_sed[k]) return fail(c, "c2r_set_sources_sed: c2r_set_sed_tables(%d) has not been called", sed);
   c->normflux_sed[k].assign(normflux, normflux + c->nsrc);
   c->s_star_sed[k] = s_star;
+  return 0;
+}
+
+// The per-frequency vectors of k_build_tables, with the host versions of the bit-exact exp / pow:
+// set_frequency_array, set_cross_section_freq_dependence and the tau-independent factors of
+// fill_photo_integrands / fill_heating_integrands_* (radiation_tables.f90:432-783).
+static void build_sed_vectors(const c2r_sed_setup &S, std::vector<double> &v) {
+  v.assign((size_t)6 * SEDV, 0.0);
+  double *csfd = v.data(), *A = csfd + SEDV, *D = A + SEDV, *H0 = D + SEDV, *H1 = H0 + SEDV, *H2 = H1 + SEDV;
+  for (int b = 0; b < NFREQ; b++) {
+    const double fmin = S.freq_min[b], df = S.delta_freq[b];
+    for (int x = 0; x <= 512; x++) {
+      const size_t q = (size_t)b * 513 + x;
+      const double freq = fmin + df * (double)(float)x;
+      csfd[q] = C2R_MATH_POW(freq / fmin, -S.xsec_index[b]);
+      if (S.sed == 0) {
+        if (freq * S.h_over_kT < 700.0) { // :474; otherwise the integrand is 0: A = 0, D = 1
+          A[q] = 4.0 * S.pi * S.R_star2 * S.two_pi_over_c_square * freq * freq;
+          D[q] = C2R_MATH_EXP(freq * S.h_over_kT) - 1.0;
+        } else {
+          A[q] = 0.0;
+          D[q] = 1.0;
+        }
+      } else {
+        A[q] = S.pl_scaling * C2R_MATH_POW(freq, -S.pl_index);
+        D[q] = 1.0; // x / 1.0 == x
+      }
+      H0[q] = S.hplanck * (freq - S.ion_freq_HI);
+      H1[q] = S.hplanck * (freq - S.ion_freq_HeI);
+      H2[q] = S.hplanck * (freq - S.ion_freq_HeII);
+    }
+  }
+}
+
+extern "C" int c2r_build_tables(c2r_ctx *c, const c2r_sed_setup *S, int with_heat) {
+  if (!c || !S) return 1;
+  if (S->nfreq != 512) return fail(c, "c2r_build_tables: nfreq = %d, the band set-up is for NumFreq = 512", S->nfreq);
+  if (S->sed < 0 || S->sed > 2) return fail(c, "c2r_build_tables: sed = %d, expected 0 (black body), 1 (power law), 2 (quasar)", S->sed);
+  if (!S->freq_min || !S->delta_freq || !S->xsec_index || !S->tau || !S->romw) return fail(c, "c2r_build_tables: null vector");
+  if (S->sed == 0 && !c->have_bands) return fail(c, "c2r_build_tables: c2r_set_tables (band vectors) has not been called");
+  if (S->sed > 0 && !c->have_sed_limits[S->sed - 1]) return fail(c, "c2r_build_tables: c2r_set_sed_tables(%d) (band range) has not been called", S->sed);
+  if (S->sed == 0 && with_heat && !c->have_fvec) return fail(c, "c2r_build_tables: heating tables need the secondary-ionisation vectors of c2r_set_tables");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<double> v;
+  build_sed_vectors(*S, v);
+  double *d_v = nullptr, *d_small = nullptr;
+  HIPCHK(c, hipMalloc(&d_v, sizeof(double) * v.size()));
+  HIPCHK(c, hipMalloc(&d_small, sizeof(double) * (NTAU + 1 + 513 + NFREQ)));
+  HIPCHK(c, hipMemcpy(d_v, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d_small, S->tau, sizeof(double) * (NTAU + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d_small + NTAU + 1, S->romw, sizeof(double) * 513, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(d_small + NTAU + 1 + 513, S->delta_freq, sizeof(double) * NFREQ, hipMemcpyHostToDevice));
+  double **tab = S->sed == 0 ? nullptr : c->d_sed_tab[S->sed - 1];
+  double **pt = S->sed == 0 ? &c->d_photo_thick : &tab[0], **pn = S->sed == 0 ? &c->d_photo_thin : &tab[1];
+  double **ht = S->sed == 0 ? &c->d_heat_thick : &tab[2], **hn = S->sed == 0 ? &c->d_heat_thin : &tab[3];
+  if (!*pt) HIPCHK(c, hipMalloc(pt, sizeof(double) * (size_t)NFREQ * NTAUP));
+  if (!*pn) HIPCHK(c, hipMalloc(pn, sizeof(double) * (size_t)NFREQ * NTAUP));
+  if (with_heat) {
+    if (!*ht) HIPCHK(c, hipMalloc(ht, sizeof(double) * (size_t)NHEAT * NTAUP));
+    if (!*hn) HIPCHK(c, hipMalloc(hn, sizeof(double) * (size_t)NHEAT * NTAUP));
+  }
+  hipLaunchKernelGGL(k_build_tables, dim3((NTAU + 1 + BLOCK - 1) / BLOCK, 2 * NFREQ), dim3(BLOCK), 0, c->stream, d_v,
+                     d_small, d_small + NTAU + 1, d_small + NTAU + 1 + 513, with_heat ? 1 : 0, *pt, *pn,
+                     with_heat ? *ht : nullptr, with_heat ? *hn : nullptr);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_v);
+  (void)hipFree(d_small);
+  if (S->sed == 0) {
+    c->have_tables = true;
+    c->have_heat_tables = with_heat != 0;
+  } else {
+    c->have_sed[S->sed - 1] = true;
+    c->have_sed_heat[S->sed - 1] = with_heat != 0;
+  }
+  return 0;
+}
+
+extern "C" int c2r_download_tables(c2r_ctx *c, int sed, double *photo_thick, double *photo_thin, double *heat_thick,
+                                   double *heat_thin) {
+  if (!c) return 1;
+  if (sed < 0 || sed > 2) return fail(c, "c2r_download_tables: sed = %d", sed);
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool have = sed == 0 ? c->have_tables : c->have_sed[sed - 1];
+  const bool have_heat = sed == 0 ? c->have_heat_tables : c->have_sed_heat[sed - 1];
+  if (!have) return fail(c, "c2r_download_tables: SED %d has no tables", sed);
+  if ((heat_thick || heat_thin) && !have_heat) return fail(c, "c2r_download_tables: SED %d has no heating tables", sed);
+  const double *src[4] = {sed == 0 ? c->d_photo_thick : c->d_sed_tab[sed - 1][0], sed == 0 ? c->d_photo_thin : c->d_sed_tab[sed - 1][1],
+                          sed == 0 ? c->d_heat_thick : c->d_sed_tab[sed - 1][2], sed == 0 ? c->d_heat_thin : c->d_sed_tab[sed - 1][3]};
+  double *dst[4] = {photo_thick, photo_thin, heat_thick, heat_thin};
+  const int ncol[4] = {NFREQ, NFREQ, NHEAT, NHEAT};
+  for (int t = 0; t < 4; t++) {
+    if (!dst[t]) continue;
+    std::vector<double> tmp((size_t)ncol[t] * NTAUP);
+    HIPCHK(c, hipMemcpy(tmp.data(), src[t], sizeof(double) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int col = 0; col < ncol[t]; col++)
+      std::memcpy(dst[t] + (size_t)col * (NTAU + 1), tmp.data() + (size_t)col * NTAUP, sizeof(double) * (NTAU + 1));
+  }
   return 0;
 }
 

@@ -58,6 +58,11 @@ class RadiationTables:
     # -DPL / -DQUASARS builds: sed[1] (power law) / sed[2] (quasar-like) =
     # dict(photo_thick, photo_thin, heat_thick, heat_thin, lower, upper)
     sed: dict = field(default_factory=dict)
+    # What spec_integration starts from (band set-up, Romberg weights, normalised SEDs; keys as in
+    # tests/golden/sed_setup.npz).  With build_on_device the tables above are ignored and the engine
+    # builds them on the GPU (c2r_build_tables) -- bit-identical to the host-built ones.
+    setup: dict | None = None
+    build_on_device: bool = False
 
     def add_sed_file(self, path):
         """pl_* / qpl_* tables and band limits as dumped from a -DPL -DQUASARS reference build."""
@@ -164,17 +169,53 @@ class HipEngine:
     # -- inputs ------------------------------------------------------------------------------
     def set_tables(self, t: RadiationTables):
         fv = None
-        if t.heat_thick is not None:
+        if t.fvec and len(t.fvec) == 12:
             arr = (C.POINTER(C.c_double) * 12)(*[_dp(t.fvec[k]) for k in FVEC_ORDER])
             fv = arr
-        self._chk(self.lib.c2r_set_tables(self.h, _dp(t.photo_thick), _dp(t.photo_thin), _dp(t.heat_thick),
-                                          _dp(t.heat_thin), _dp(t.sigma_HI), _dp(t.sigma_HeI), _dp(t.sigma_HeII),
-                                          fv, int(t.bb_upper)))
+        on_dev = bool(t.build_on_device)
+        if on_dev and t.setup is None:
+            raise C2RayHipError("build_on_device needs RadiationTables.setup")
+        heat = t.heat_thick is not None or (on_dev and fv is not None)
+        self._chk(self.lib.c2r_set_tables(self.h, None if on_dev else _dp(t.photo_thick), None if on_dev else _dp(t.photo_thin),
+                                          None if on_dev else _dp(t.heat_thick), None if on_dev else _dp(t.heat_thin),
+                                          _dp(t.sigma_HI), _dp(t.sigma_HeI), _dp(t.sigma_HeII), fv, int(t.bb_upper)))
+        if on_dev:
+            self.build_tables(t.setup, 0, heat)
         if t.cool is not None:
             self._chk(self.lib.c2r_set_cooling(self.h, _dp(t.cool), float(t.cool_mintemp), float(t.cool_dtemp)))
         for idx, d in t.sed.items():
-            self._chk(self.lib.c2r_set_sed_tables(self.h, int(idx), _dp(d["photo_thick"]), _dp(d["photo_thin"]),
-                                                  _dp(d["heat_thick"]), _dp(d["heat_thin"]), d["lower"], d["upper"]))
+            if on_dev:
+                self._chk(self.lib.c2r_set_sed_tables(self.h, int(idx), None, None, None, None, d["lower"], d["upper"]))
+                self.build_tables(t.setup, int(idx), heat)
+            else:
+                self._chk(self.lib.c2r_set_sed_tables(self.h, int(idx), _dp(d["photo_thick"]), _dp(d["photo_thin"]),
+                                                      _dp(d["heat_thick"]), _dp(d["heat_thin"]), d["lower"], d["upper"]))
+
+    def build_tables(self, d, sed=0, heat=True):
+        """spec_integration on the device (c2r_build_tables) from a set-up dictionary."""
+        from ._lib import SedSetup
+        b = np.arange(1, 48)
+        xi = _f64(np.where(b <= 1, d["pl_index_HI"], np.where(b <= 27, d["pl_index_HeI"], d["pl_index_HeII"])))
+        keep = [_f64(d[k]) for k in ("freq_min", "delta_freq", "tau", "romw9")] + [xi]
+        s = SedSetup()
+        s.nfreq, s.sed = 512, int(sed)
+        s.freq_min, s.delta_freq, s.tau, s.romw, s.xsec_index = (_dp(a) for a in keep)
+        s.R_star2, s.h_over_kT, s.two_pi_over_c_square = (float(x) for x in d["sed_setup"])
+        c = d["consts"]
+        s.pi, s.hplanck = float(c[0]), float(c[5])
+        s.ion_freq_HI, s.ion_freq_HeI, s.ion_freq_HeII = float(c[22]), float(c[23]), float(c[24])
+        if sed:
+            s.pl_scaling, s.pl_index = (float(x) for x in d["pl_setup" if sed == 1 else "qpl_setup"])
+        self._chk(self.lib.c2r_build_tables(self.h, C.byref(s), int(bool(heat))))
+
+    def download_tables(self, sed=0, heat=True):
+        nt = 2001
+        out = {"photo_thick": np.empty(47 * nt), "photo_thin": np.empty(47 * nt)}
+        if heat:
+            out.update(heat_thick=np.empty(113 * nt), heat_thin=np.empty(113 * nt))
+        self._chk(self.lib.c2r_download_tables(self.h, int(sed), _dp(out["photo_thick"]), _dp(out["photo_thin"]),
+                                               _dp(out.get("heat_thick")), _dp(out.get("heat_thin"))))
+        return out
 
     def set_step(self, mat: Material, grid: GridProps, cosmo: Cosmology):
         nd = _f64(mat.ndens).reshape(-1)

@@ -40,6 +40,8 @@ const char *c2r_create_error(void);
  * the twelve secondary-ionisation vectors f1ion_HI .. f2heat_HeII, each (2:47) = 46 doubles, in the
  * order f1ion_{HI,HeI,HeII}, f2ion_{..}, f1heat_{..}, f2heat_{..} (may be NULL with the heat tables),
  * and bb_FreqBnd_UpperLimit (radiation_tables.f90:193-199). */
+/* photo_thick/photo_thin and heat_thick/heat_thin may be NULL: the call then only sets the band vectors and
+ * c2r_build_tables makes the tables on the device. */
 int c2r_set_tables(c2r_ctx *ctx, const double *photo_thick, const double *photo_thin,
                    const double *heat_thick, const double *heat_thin, const double *sigma_HI,
                    const double *sigma_HeI, const double *sigma_HeII, const double *const fvec[12],
@@ -58,6 +60,31 @@ int c2r_set_cooling(c2r_ctx *ctx, const double *cool5x801, double mintemp, doubl
 int c2r_set_step(c2r_ctx *ctx, const double *ndens, const double dr[3], double vol, float clumping,
                  double zred, double H0, double Omega0, int isothermal, double temper_val,
                  const double reccoef[12]);
+
+/* Table construction on the device: spec_integration (radiation_tables.f90:172-422) for one SED from what
+ * spectrum_parms, setup_scalingfactors (radiation_sizes.f90:62-688), romberg_initialisation(NumFreq)
+ * (romberg.f90:24-92) and normalize_seds leave behind.  All of it is public module data of the reference:
+ *   freq_min, delta_freq (47)          radiation_sizes
+ *   xsec_index (47)                    cross_section_HI_powerlaw_index(1), ..HeI..(2:27), ..HeII..(28:47), the
+ *                                      index spec_integration passes per band (radiation_tables.f90:278,315,349)
+ *   tau (0:NumTau)                     radiation_tables:tau, romw = romberg:romw(0:NumFreq, 9)
+ *   R_star2, h_over_kT                 radiation_sed_parameters (black body); pl_scaling/pl_index or
+ *                                      qpl_scaling/qpl_index for sed = 1 / 2
+ *   two_pi_over_c_square, hplanck (cgsconstants), pi (mathconstants), ion_freq_* (cgsphotoconstants)
+ * The band vectors (c2r_set_tables with NULL tables) or the band range (c2r_set_sed_tables with NULL tables)
+ * must have been given before.  Results are bit-identical to the reference's host-built tables.
+ * c2r_download_tables returns tables in the reference's layout (0:NumTau, ncol); pointers may be NULL. */
+typedef struct c2r_sed_setup {
+  int nfreq;                /* NumFreq = 512 */
+  int sed;                  /* 0 black body, 1 power law, 2 quasar-like power law */
+  const double *freq_min, *delta_freq, *xsec_index, *tau, *romw;
+  double R_star2, h_over_kT, two_pi_over_c_square, hplanck, pi;
+  double ion_freq_HI, ion_freq_HeI, ion_freq_HeII;
+  double pl_scaling, pl_index;
+} c2r_sed_setup;
+int c2r_build_tables(c2r_ctx *ctx, const c2r_sed_setup *setup, int with_heat);
+int c2r_download_tables(c2r_ctx *ctx, int sed, double *photo_thick, double *photo_thin, double *heat_thick,
+                        double *heat_thin);
 
 /* Lyman-limit systems (c2ray_parameters.f90:72-78 use_LLS, type_of_LLS): a fog of unresolved absorbers added
  * to the incoming HI column of every cell but the source's, coldensh_in += coldensh_LLS*path/dr(1)
