@@ -16,6 +16,15 @@ module c2ray_hip
      integer(c_long_long) :: cells_swept
   end type c2r_timing
 
+  !> c2r_sed_setup of include/c2ray_hip.h: what spec_integration starts from for one SED
+  type, bind(C) :: c2r_sed_setup
+     integer(c_int) :: nfreq, sed
+     type(c_ptr) :: freq_min, delta_freq, xsec_index, tau, romw
+     real(c_double) :: R_star2, h_over_kT, two_pi_over_c_square, hplanck, pi
+     real(c_double) :: ion_freq_HI, ion_freq_HeI, ion_freq_HeII
+     real(c_double) :: pl_scaling, pl_index
+  end type c2r_sed_setup
+
   interface
 
      integer(c_int) function c2r_create(ctx, device, mesh) bind(C, name="c2r_create")
@@ -43,7 +52,7 @@ module c2ray_hip
           sigma_HI, sigma_HeI, sigma_HeII, fvec, bb_upper) bind(C, name="c2r_set_tables")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
-       real(c_double), intent(in) :: photo_thick(*), photo_thin(*)
+       type(c_ptr), value :: photo_thick, photo_thin ! c_loc of the tables, or c_null_ptr (c2r_build_tables)
        type(c_ptr), value :: heat_thick, heat_thin   ! c_loc of the tables, or c_null_ptr
        real(c_double), intent(in) :: sigma_HI(*), sigma_HeI(*), sigma_HeII(*)
        type(c_ptr), intent(in) :: fvec(12)           ! c_loc of the twelve f vectors
@@ -85,7 +94,7 @@ module c2ray_hip
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
        integer(c_int), value :: sed
-       real(c_double), intent(in) :: photo_thick(*), photo_thin(*)
+       type(c_ptr), value :: photo_thick, photo_thin ! c_loc of the tables, or c_null_ptr (c2r_build_tables)
        type(c_ptr), value :: heat_thick, heat_thin
        integer(c_int), value :: lower, upper
      end function c2r_set_sed_tables
@@ -97,6 +106,21 @@ module c2ray_hip
        real(c_double), intent(in) :: normflux(*)
        real(c_double), value :: s_star
      end function c2r_set_sources_sed
+
+     integer(c_int) function c2r_build_tables(ctx, setup, with_heat) bind(C, name="c2r_build_tables")
+       import :: c_int, c_ptr, c2r_sed_setup
+       type(c_ptr), value :: ctx
+       type(c2r_sed_setup), intent(in) :: setup
+       integer(c_int), value :: with_heat
+     end function c2r_build_tables
+
+     integer(c_int) function c2r_download_tables(ctx, sed, photo_thick, photo_thin, heat_thick, heat_thin) &
+          bind(C, name="c2r_download_tables")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: sed
+       type(c_ptr), value :: photo_thick, photo_thin, heat_thick, heat_thin  ! (0:NumTau, ncol) or c_null_ptr
+     end function c2r_download_tables
 
      integer(c_int) function c2r_set_lls(ctx, use_lls, coldensh_lls, lls_grid) bind(C, name="c2r_set_lls")
        import :: c_int, c_ptr, c_double
@@ -150,6 +174,29 @@ module c2ray_hip
        type(c_ptr), value :: ctx
        integer(c_int), value :: first, stride
      end function c2r_pass_sources
+
+     integer(c_int) function c2r_pass_sources_begin(ctx, first, stride, nslab) bind(C, name="c2r_pass_sources_begin")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: first, stride, nslab
+     end function c2r_pass_sources_begin
+
+     integer(c_int) function c2r_pass_slab_count(ctx) bind(C, name="c2r_pass_slab_count")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_pass_slab_count
+
+     integer(c_int) function c2r_pass_wait_slab(ctx, slab, first_cell, ncells) bind(C, name="c2r_pass_wait_slab")
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: slab
+       integer(c_size_t), intent(out) :: first_cell, ncells
+     end function c2r_pass_wait_slab
+
+     integer(c_int) function c2r_pass_sources_end(ctx) bind(C, name="c2r_pass_sources_end")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_pass_sources_end
 
      integer(c_int) function c2r_do_source(ctx, ns) bind(C, name="c2r_do_source")
        import :: c_int, c_ptr

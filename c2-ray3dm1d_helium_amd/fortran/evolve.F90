@@ -476,44 +476,75 @@ contains
   subroutine upload_tables ()
 
     type(c_ptr) :: fvec(12)
-    type(c_ptr) :: ht, hn
+    type(c_ptr) :: pt, pn, ht, hn
     real(kind=dp) :: cool(801,5)
     real(kind=dp) :: mintemp, dtemp
+    logical :: device_tables, heat
+    character(len=8) :: value
+    integer :: length, status
 
-    if (allocated(bb_heat_thick_table) .and. allocated(f1ion_HI)) then
-       ht = c_loc_2d (bb_heat_thick_table)
-       hn = c_loc_2d (bb_heat_thin_table)
+    ! C2RAY_HIP_BUILD_TABLES=1: the photo-ionisation and heating tables are integrated on the device
+    ! (c2r_build_tables) from the band set-up instead of being copied from rad_ini's host arrays
+    call get_environment_variable("C2RAY_HIP_BUILD_TABLES", value, length, status)
+    device_tables = (status == 0 .and. length > 0 .and. value(1:1) == "1")
+
+    heat = allocated(bb_heat_thick_table) .and. allocated(f1ion_HI)
+    pt = c_null_ptr
+    pn = c_null_ptr
+    ht = c_null_ptr
+    hn = c_null_ptr
+    fvec(:) = c_null_ptr
+    if (.not.device_tables) then
+       pt = c_loc_2d (bb_photo_thick_table)
+       pn = c_loc_2d (bb_photo_thin_table)
+    endif
+    if (heat) then
+       if (.not.device_tables) then
+          ht = c_loc_2d (bb_heat_thick_table)
+          hn = c_loc_2d (bb_heat_thin_table)
+       endif
        fvec = (/ c_loc_1d(f1ion_HI), c_loc_1d(f1ion_HeI), c_loc_1d(f1ion_HeII), &
             c_loc_1d(f2ion_HI), c_loc_1d(f2ion_HeI), c_loc_1d(f2ion_HeII), &
             c_loc_1d(f1heat_HI), c_loc_1d(f1heat_HeI), c_loc_1d(f1heat_HeII), &
             c_loc_1d(f2heat_HI), c_loc_1d(f2heat_HeI), c_loc_1d(f2heat_HeII) /)
-    else
-       ht = c_null_ptr
-       hn = c_null_ptr
-       fvec(:) = c_null_ptr
     endif
-    call check (c2r_set_tables (hip_ctx, bb_photo_thick_table, bb_photo_thin_table, ht, hn, &
+    call check (c2r_set_tables (hip_ctx, pt, pn, ht, hn, &
          sigma_HI, sigma_HeI, sigma_HeII, fvec, int(bb_FreqBnd_UpperLimit,c_int)), "c2r_set_tables")
+    if (device_tables) call build_tables_on_device (0, heat)
 
 #ifdef PL
+    pt = c_null_ptr
+    pn = c_null_ptr
     ht = c_null_ptr
     hn = c_null_ptr
-    if (allocated(pl_heat_thick_table)) then
-       ht = c_loc_2d (pl_heat_thick_table)
-       hn = c_loc_2d (pl_heat_thin_table)
+    if (.not.device_tables) then
+       pt = c_loc_2d (pl_photo_thick_table)
+       pn = c_loc_2d (pl_photo_thin_table)
+       if (allocated(pl_heat_thick_table)) then
+          ht = c_loc_2d (pl_heat_thick_table)
+          hn = c_loc_2d (pl_heat_thin_table)
+       endif
     endif
-    call check (c2r_set_sed_tables (hip_ctx, 1_c_int, pl_photo_thick_table, pl_photo_thin_table, ht, hn, &
+    call check (c2r_set_sed_tables (hip_ctx, 1_c_int, pt, pn, ht, hn, &
          int(pl_FreqBnd_LowerLimit,c_int), int(pl_FreqBnd_UpperLimit,c_int)), "c2r_set_sed_tables")
+    if (device_tables) call build_tables_on_device (1, heat)
 #endif
 #ifdef QUASARS
+    pt = c_null_ptr
+    pn = c_null_ptr
     ht = c_null_ptr
     hn = c_null_ptr
-    if (allocated(qpl_heat_thick_table)) then
-       ht = c_loc_2d (qpl_heat_thick_table)
-       hn = c_loc_2d (qpl_heat_thin_table)
+    if (.not.device_tables) then
+       pt = c_loc_2d (qpl_photo_thick_table)
+       pn = c_loc_2d (qpl_photo_thin_table)
+       if (allocated(qpl_heat_thick_table)) then
+          ht = c_loc_2d (qpl_heat_thick_table)
+          hn = c_loc_2d (qpl_heat_thin_table)
+       endif
     endif
-    call check (c2r_set_sed_tables (hip_ctx, 2_c_int, qpl_photo_thick_table, qpl_photo_thin_table, ht, hn, &
+    call check (c2r_set_sed_tables (hip_ctx, 2_c_int, pt, pn, ht, hn, &
          int(qpl_FreqBnd_LowerLimit,c_int), int(qpl_FreqBnd_UpperLimit,c_int)), "c2r_set_sed_tables")
+    if (device_tables) call build_tables_on_device (2, heat)
 #endif
 
     if (.not.isothermal) then
@@ -527,6 +558,88 @@ contains
   end subroutine upload_tables
 
   ! ===========================================================================
+
+  !> spec_integration (radiation_tables.f90:172-422) on the device for SED `sed` (0 BB, 1 PL, 2 QPL), from
+  !! the public module data that spectrum_parms, setup_scalingfactors, romberg_initialisation and
+  !! normalize_seds have set up
+  subroutine build_tables_on_device (sed, heat)
+
+    use mathconstants, only: pi
+    use cgsconstants, only: hplanck, two_pi_over_c_square
+    use cgsphotoconstants, only: ion_freq_HI, ion_freq_HeI, ion_freq_HeII
+    use radiation_sizes, only: NumFreq, NumBndin1, NumBndin2, freq_min, delta_freq
+    use radiation_sizes, only: cross_section_HI_powerlaw_index, cross_section_HeI_powerlaw_index
+    use radiation_sizes, only: cross_section_HeII_powerlaw_index
+    use radiation_sed_parameters, only: R_star2, h_over_kT
+#ifdef PL
+    use radiation_sed_parameters, only: pl_scaling, pl_index
+#endif
+#ifdef QUASARS
+    use radiation_sed_parameters, only: qpl_scaling, qpl_index
+#endif
+    use radiation_tables, only: tau
+    use romberg, only: romw
+
+    integer,intent(in) :: sed
+    logical,intent(in) :: heat
+
+    type(c2r_sed_setup) :: setup
+    real(kind=dp),dimension(NumFreqBnd),target,save :: xsec_index
+    real(kind=dp),dimension(:),allocatable,target,save :: tau_copy, romw_copy
+    integer :: b
+    integer(c_int) :: with_heat
+
+    ! the index spec_integration passes per band (radiation_tables.f90:278,315,349)
+    do b=1,NumFreqBnd
+       if (b <= NumBndin1) then
+          xsec_index(b)=cross_section_HI_powerlaw_index(b)
+       elseif (b <= NumBndin1+NumBndin2) then
+          xsec_index(b)=cross_section_HeI_powerlaw_index(b)
+       else
+          xsec_index(b)=cross_section_HeII_powerlaw_index(b)
+       endif
+    enddo
+    if (.not.allocated(tau_copy)) allocate(tau_copy(size(tau)),romw_copy(NumFreq+1))
+    tau_copy(:)=tau(:)
+    romw_copy(:)=romw(0:NumFreq,nint(log(real(NumFreq,dp))/log(2.0)))
+
+    setup%nfreq=NumFreq
+    setup%sed=sed
+    setup%freq_min=c_loc_1d(freq_min)
+    setup%delta_freq=c_loc_1d(delta_freq)
+    setup%xsec_index=c_loc(xsec_index)
+    setup%tau=c_loc(tau_copy)
+    setup%romw=c_loc(romw_copy)
+    setup%R_star2=R_star2
+    setup%h_over_kT=h_over_kT
+    setup%two_pi_over_c_square=two_pi_over_c_square
+    setup%hplanck=hplanck
+    setup%pi=pi
+    setup%ion_freq_HI=ion_freq_HI
+    setup%ion_freq_HeI=ion_freq_HeI
+    setup%ion_freq_HeII=ion_freq_HeII
+    setup%pl_scaling=1.0_dp
+    setup%pl_index=1.0_dp
+#ifdef PL
+    if (sed == 1) then
+       setup%pl_scaling=pl_scaling
+       setup%pl_index=pl_index
+    endif
+#endif
+#ifdef QUASARS
+    if (sed == 2) then
+       setup%pl_scaling=qpl_scaling
+       setup%pl_index=qpl_index
+    endif
+#endif
+    with_heat=0
+    if (heat) with_heat=1
+    call check (c2r_build_tables (hip_ctx, setup, with_heat), "c2r_build_tables")
+    if (rank == 0) write(logf,"(A,I2)") "c2ray_hip: photo-ionisation and heating tables built on the device for SED ", sed
+
+  end subroutine build_tables_on_device
+
+  !----------------------------------------------------------------------------
 
   subroutine read_cooling_tables (cool, mintemp, dtemp)
 

@@ -24,18 +24,24 @@ sys.path.insert(0, str(ROOT / "oracle"))
     # C2Ray_3D_hip_dogrid: the reference's own master_slave.F90 (unmodified) deals out the sources and calls
     # do_source of the product's module evolve_source -- the do_source call surface, one source per call
     (False, "dogrid", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
+    # C2RAY_HIP_BUILD_TABLES=1: the shim has the photo-ionisation / heating tables integrated on the device
+    # (c2r_build_tables) instead of uploading rad_ini's host arrays
+    (False, "devtables", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     (True, False, [(8, 8, 8, 1e55)]),
     # the -DPL -DQUASARS build (the flags of the reference's production targets, Makefile:185-186,207-208)
     (False, True, [(8, 8, 8, 1e55, 3e54, 0.0), (2, 15, 4, 0.0, 2e54, 4e54), (16, 1, 9, 2e54, 0.0, 1e54)]),
 ])
-def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, sources):
+def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, sources, monkeypatch):
     import refrun
+    if pl == "devtables":
+        monkeypatch.setenv("C2RAY_HIP_BUILD_TABLES", "1")
+    devtables = pl == "devtables"
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
     which_hip = "hip_dogrid" if dogrid else "hip"
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "")
     r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl, lls=lls)
     r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls)
     files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
@@ -44,6 +50,8 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), f
     # same iteration history in the log
     assert refrun.parse_log(r1) == refrun.parse_log(r2)
+    if devtables:
+        assert "tables built on the device for SED  0" in (r2 / "results" / "C2Ray.log").read_text(errors="replace")
     # photon statistics (written from host arrays the HIP path filled): compare the numbers
     a = (r1 / "results" / "PhotonCounts2.out").read_text().split()
     b = (r2 / "results" / "PhotonCounts2.out").read_text().split()
