@@ -681,3 +681,37 @@ def test_table_construction_on_device(pkg, gold):
     ev = pkg.Evolve(mesh, tb, device=0)
     niter = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
     assert niter == len(o["conv_flags"]) and np.array_equal(mat.xh, o["xh"]) and np.array_equal(mat.temperature_grid, o["temperature"])
+
+
+def test_no_sources_runs_501_global_passes(pkg, orc, otables, tables):
+    """evolve3D with NumSrc = 0 (evolve.F90:147,163,177): conv_criterion = min(..., 0) = 0 is never beaten, so
+    the loop runs into the 500-iteration cap -- 501 global passes of pure recombination.  Same on the
+    device as in the oracle, bit for bit."""
+    n = 12
+    rng = np.random.default_rng(3)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc)) * 300.0
+    x = 10.0 ** rng.uniform(-3, -0.05, nc)
+    xh, xhe = np.concatenate([1.0 - x, x]), np.concatenate([1.0 - x, 0.7 * x, 0.3 * x])
+    mat = pkg.Material(ndens, xh.copy(), xhe.copy(), None, True, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(np.zeros((0, 3), dtype=np.int32), np.zeros(0), 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    dt = 3.0e7 * hp.YEAR
+    ev = pkg.Evolve((n, n, n), tables, device=0)
+    niter = ev.evolve3D(0.0, dt, 0, mat, grid, src, cosmo)
+    st = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, True, 1.0e4, 1.0, np.zeros((0, 3), dtype=np.int32), np.zeros(0),
+                  1.0e48, ndens, hp.reccoef(1.0e4))
+    s = orc.State(st, xh, xhe)
+    assert orc.evolve3d(otables, st, s, dt) == 501 == niter
+    assert ev.conv_flags == s.conv_flags
+    assert np.array_equal(mat.xh, s.xh) and np.array_equal(mat.xhe, s.xhe)
+    # the loop leaves through the iteration cap, which skips the final xh = xh_intermed (evolve.F90:177-181):
+    # xh is untouched, the recombined state sits in xh_intermed
+    assert np.array_equal(mat.xh, xh)
+    it = ev.iter_state
+    assert np.array_equal(it["xh_intermed"], s.xh_intermed) and np.all(it["xh_intermed"][nc:] < x)
+    assert not np.any(ev.rates["phih_grid"])
