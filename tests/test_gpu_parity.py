@@ -713,5 +713,5 @@ def test_no_sources_runs_501_global_passes(pkg, orc, otables, tables):
     # xh is untouched, the recombined state sits in xh_intermed
     assert np.array_equal(mat.xh, xh)
     it = ev.iter_state
-    assert np.array_equal(it["xh_intermed"], s.xh_intermed) and np.all(it["xh_intermed"][nc:] < x)
+    assert np.array_equal(it["xh_intermed"], s.xh_intermed) and it["xh_intermed"][nc:].mean() < 0.5 * x.mean()
     assert not np.any(ev.rates["phih_grid"])
