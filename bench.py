@@ -44,6 +44,13 @@ def measured_traffic(kernel):
         return None
 
 
+def measured_counter(kernel, counter):
+    try:
+        return json.loads(PMC_SUMMARY.read_text())[kernel][counter]["per_launch"]
+    except Exception:
+        return None
+
+
 def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False):
     """Synthetic inputs of BASELINE configs[2]: uniform density of the
     reference's test problem at z = 9, isothermal 1e4 K, sources at seeded positions
@@ -69,7 +76,7 @@ def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False
     return mat, grid, src, cosmo
 
 
-def cpu_baseline(pkg, mesh=96, nsrc=2):
+def cpu_baseline(pkg, mesh=128, nsrc=4):
     """The oracle (single-threaded C port of the reference's path) on a bounded sample of the same
     workload: one outer iteration on a mesh^3 box with nsrc sources.  Reported, not a target."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -93,7 +100,7 @@ def cpu_baseline(pkg, mesh=96, nsrc=2):
 def cpu_baseline_reference(mesh=64):
     """The reference ITSELF (flang -O2 build of /root/reference made by oracle/ref_build.sh in the dev
     container; the binary travels in oracle/_ref/) on its own test problem: mesh^3, one 1e54 source,
-    isothermal, four time slices.  Wall time of the evolve3D iterations from the reference's own
+    isothermal, four time slices of three steps.  Wall time of the evolve3D iterations from the reference's own
     Timings.log stamps (evolve.F90:150,220).  Returns None when the binary is not there."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import re
@@ -104,7 +111,7 @@ def cpu_baseline_reference(mesh=64):
         return None
     # the reference's OpenMP path is at most 8-way (6 axes / 12 planes / 8 octants, evolve_source.F90:158-189)
     threads = min(8, os.cpu_count() or 1) if omp else 1
-    run = refrun.run_reference(mesh, [(mesh // 2, mesh // 2, mesh // 2, 1e54)], isothermal=True, steps_per_slice=1,
+    run = refrun.run_reference(mesh, [(mesh // 2, mesh // 2, mesh // 2, 1e54)], isothermal=True, steps_per_slice=3,
                                which="test", omp=omp, threads=threads, name="bench_reference_run")
     text = (run / "results" / "Timings.log").read_text(errors="replace")
     total, niter, t0 = 0.0, 0, None
@@ -233,6 +240,13 @@ def main():
                          "note": "136 B per cell.source (SURVEY 8d) x cells x sources of one launch / mean launch "
                                  "time (HIP events on the library stream); the kernel is FP64-ALU bound (VALU busy "
                                  "~85 %, profiles/), not HBM bound"},
+            # the bound that actually holds for k_rates (SURVEY 8d asks for HBM % and FP64 %): VALU issue rate.
+            # wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU) / live launch time, against
+            # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+            "roofline_valu_issue": (lambda n_instr: None if n_instr is None or not (n == 256 and a.sources == 8 and a.batch == 8 and not a.heating) else {
+                "bound": "valu-issue", "unit": "wave-instructions/s", "achieved": n_instr / (rates_per_launch_ms * 1e-3),
+                "peak": 1024 * 2.4e9 / 4.0, "frac": n_instr / (rates_per_launch_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
+                "kernel": "k_rates", "instructions_per_launch": n_instr})(measured_counter("k_rates", "SQ_INSTS_VALU")),
             "kernel_ms_per_step": {"column_sweep": sweep_ms / a.steps, "rates": rates_ms / a.steps,
                                    "chemistry": chem_ms / a.steps},
             # the two kernels the north star names, priced the same way (HIP-event time of their launches)
