@@ -7,7 +7,11 @@
 //   rates          k_rates         all cells x all sources of the batch, no dependencies:
 //                                  photoion_rates + accumulation into the rate grids in source order
 //                                  (evolve0D, second half)
+//   boundary loss  k_loss_exact    full photon loss through a sub-box surface from the stored columns, when
+//                                  the 1/16 sample taken inside the sweep did not decide the while-test
 //   chemistry      k_chemistry     evolve0D_global / do_chemistry / doric / thermal per cell
+//   statistics     k_state_sums, k_total_rates, k_stat_finish   the grid sums of photonstatistics.f90
+//   tables         k_build_tables  spec_integration: the photo-ionisation / heating tables of one SED
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
@@ -770,11 +774,6 @@ struct c2r_ctx {
   std::vector<hipEvent_t> ev_pool; // timing events, grown on demand
   size_t ev_used = 0;
 
-  // LDS bytes requested (not used) by each rates block: caps the rates kernel at
-  // floor(160 KiB / rates_lds) blocks per CU so that waves of the next batch's column sweep can be
-  // co-resident on the same SIMDs (the sweep is memory-bound, the rates kernel ALU-bound)
-  unsigned rates_lds = 0;
-
   // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
   bool pass_open = false;
   int pass_slabs = 0;
@@ -882,7 +881,6 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMemset(c->d_rc_last, 0, sizeof(double) * 12));
   CR(hipMalloc(&c->d_stat, sizeof(double) * (STAT_BLOCKS * 5 + 8)));
   CR(hipHostMalloc(&c->h_stat, sizeof(double) * 8));
-  if (const char *e = getenv("C2R_RATES_LDS")) c->rates_lds = (unsigned)atoi(e);
   c->rates_count = 4 * nc + C2R_NFREQ + 1;
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
@@ -1597,7 +1595,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       }
     }
 #define C2R_LAUNCH_RATES(H, M)                                                                               \
-  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), c->rates_lds, c->stream2, g, ba, sc, c->d_ndens,  \
+  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), 0, c->stream2, g, ba, sc, c->d_ndens,  \
                      c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates, d_tiles, base_)
     const bool last_batch = b0 + c->batch >= mine.size();
     const int pieces = (last_batch && ns_eff > 0) ? ns_eff : 1;
