@@ -431,6 +431,25 @@ struct PhotoOut {
   double photo_out;                       // photons leaving the cell (all bands)
 };
 
+// Ricotti et al. 2002 secondary-ionisation parameters (radiation_photoionrates.f90:49-55, :558-564).
+// They depend on the cell's ionised fraction only, so a kernel that loops over sources evaluates them
+// once per cell (12 pow) and hands them to every photoion_rates call of that cell.
+struct Ricotti {
+  double y1R[3], y2R[3];
+};
+C2R_HD Ricotti ricotti_parameters(double i_state) {
+  const double CR1[3] = {0.3908, 0.0554, 1.0}, bR1[3] = {0.4092, 0.4614, 0.2663},
+               dR1[3] = {1.7592, 1.6660, 1.3163};
+  const double CR2[3] = {0.6941, 0.0984, 3.9811}, aR2[3] = {0.2, 0.2, 0.4}, bR2[3] = {0.38, 0.38, 0.34};
+  Ricotti R;
+  for (int i = 0; i < 3; i++) {
+    R.y1R[i] = CR1[i] * C2R_MATH_POW(1.0 - C2R_MATH_POW(i_state, bR1[i]), dR1[i]);
+    double xeb = 1.0 - C2R_MATH_POW(i_state, bR2[i]);
+    R.y2R[i] = CR2[i] * C2R_MATH_POW(i_state, aR2[i]) * xeb * xeb;
+  }
+  return R;
+}
+
 // radiation_photoionrates.f90:108-277 photoion_rates with its callees photo_lookuptable (:331-464),
 // heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands.
 // Band-local quantities are computed in the reference's order; sums over bands run b = 1..bb_upper
@@ -439,7 +458,7 @@ template <bool HEAT>
 C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                            const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
                            double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                           double NFlux, double i_state, PhotoOut &o) {
+                           double NFlux, const Ricotti &ric, PhotoOut &o) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
@@ -451,18 +470,7 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
 
   double f_heat = 0.0, f_ion_HI = 0.0, f_ion_HeI = 0.0;
   double df_ion_HI = 0.0, df_ion_HeI = 0.0;
-  double y1R[3], y2R[3];
-  if (HEAT) {
-    // Ricotti et al. 2002 secondary ionisation parameters (:49-55, :558-564)
-    const double CR1[3] = {0.3908, 0.0554, 1.0}, bR1[3] = {0.4092, 0.4614, 0.2663},
-                 dR1[3] = {1.7592, 1.6660, 1.3163};
-    const double CR2[3] = {0.6941, 0.0984, 3.9811}, aR2[3] = {0.2, 0.2, 0.4}, bR2[3] = {0.38, 0.38, 0.34};
-    for (int i = 0; i < 3; i++) {
-      y1R[i] = CR1[i] * C2R_MATH_POW(1.0 - C2R_MATH_POW(i_state, bR1[i]), dR1[i]);
-      double xeb = 1.0 - C2R_MATH_POW(i_state, bR2[i]);
-      y2R[i] = CR2[i] * C2R_MATH_POW(i_state, aR2[i]) * xeb * xeb;
-    }
-  }
+  const double *y1R = ric.y1R, *y2R = ric.y2R;
 
   const int nb = bd.bb_upper;
   for (int b = 0; b < nb; b++) { // b is 0-based here; reference band = b+1
@@ -624,7 +632,7 @@ struct SedSet {
 template <bool HEAT>
 C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                                  double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
-                                 double i_state, PhotoOut &o) {
+                                 const Ricotti &ric, PhotoOut &o) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
@@ -642,17 +650,7 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
   double P_HI[NSED] = {0, 0, 0}, P_HeI[NSED] = {0, 0, 0}, P_HeII[NSED] = {0, 0, 0}, P_out[NSED] = {0, 0, 0};
   double f_heat[NSED] = {0, 0, 0}, f_ion_HI[NSED] = {0, 0, 0}, f_ion_HeI[NSED] = {0, 0, 0};
   double df_ion_HI[NSED] = {0, 0, 0}, df_ion_HeI[NSED] = {0, 0, 0};
-  double y1R[3], y2R[3];
-  if (HEAT) {
-    const double CR1[3] = {0.3908, 0.0554, 1.0}, bR1[3] = {0.4092, 0.4614, 0.2663},
-                 dR1[3] = {1.7592, 1.6660, 1.3163};
-    const double CR2[3] = {0.6941, 0.0984, 3.9811}, aR2[3] = {0.2, 0.2, 0.4}, bR2[3] = {0.38, 0.38, 0.34};
-    for (int i = 0; i < 3; i++) {
-      y1R[i] = CR1[i] * C2R_MATH_POW(1.0 - C2R_MATH_POW(i_state, bR1[i]), dR1[i]);
-      double xeb = 1.0 - C2R_MATH_POW(i_state, bR2[i]);
-      y2R[i] = CR2[i] * C2R_MATH_POW(i_state, aR2[i]) * xeb * xeb;
-    }
-  }
+  const double *y1R = ric.y1R, *y2R = ric.y2R;
   for (int b = blo; b < bhi; b++) {
     bool any = false;
     for (int s = 0; s < NSED; s++) any = any || (act[s] && b >= ss.lo[s] && b < ss.hi[s]);

@@ -397,6 +397,10 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
   const double he0 = dmax(xhe_av[q], epsilon), he1 = dmax(xhe_av[q + nc], epsilon);
   double a_HI = rates[q], a_HeI = rates[q + nc], a_HeII = rates[q + 2 * nc];
   double a_heat = HEAT ? rates[q + 3 * nc] : 0.0;
+  // secondary-ionisation parameters of this cell, i_state = h_av(1) (evolve_point.F90:255): once per cell,
+  // not once per source
+  Ricotti ric = {};
+  if (HEAT) ric = ricotti_parameters(h1);
   bool touched = false;
   for (int b = 0; b < ba.n; b++) {
     const SrcInfo &S = ba.s[b];
@@ -429,10 +433,10 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
       PhotoOut o;
       if (MULTI) {
         const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, h1, o);
+        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o);
       } else {
         photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
-                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, h1, o);
+                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o);
       }
       a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
       a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);

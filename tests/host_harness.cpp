@@ -59,12 +59,14 @@ void hh_reccoef(double temperature, double *out12) {
 // out5 = photo_HI, photo_HeI, photo_HeII, heat, photo_out
 void hh_photoion(const double *cin6, double vol, double nflux, double i_state, int heat, double *out5) {
   PhotoOut o;
+  Ricotti ric = {};
+  if (heat) ric = ricotti_parameters(i_state);
   if (heat)
     photoion_rates<true>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick.data(), T.hthin.data(), cin6[0], cin6[1],
-                         cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, i_state, o);
+                         cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, ric, o);
   else
     photoion_rates<false>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick.data(), T.hthin.data(), cin6[0], cin6[1],
-                          cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, i_state, o);
+                          cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, ric, o);
   out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
 }
 
@@ -98,8 +100,10 @@ static SedSet make_sedset() {
 void hh_photoion_multi(const double *cin6, double vol, const double *nflux3, double i_state, int heat, double *out5) {
   PhotoOut o;
   const SedSet ss = make_sedset();
-  if (heat) photoion_rates_multi<true>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, i_state, o);
-  else photoion_rates_multi<false>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, i_state, o);
+  Ricotti ric = {};
+  if (heat) ric = ricotti_parameters(i_state);
+  if (heat) photoion_rates_multi<true>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, ric, o);
+  else photoion_rates_multi<false>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, ric, o);
   out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
 }
 double hh_photo_out_multi(const double *cin6, const double *nflux3) {
