@@ -827,8 +827,17 @@ static int alloc_col(c2r_ctx *c) {
   if (c->d_col && c->col_slots >= (size_t)c->batch) return 0;
   if (c->d_col) HIPCHK(c, hipFree(c->d_col));
   c->d_col = nullptr;
-  HIPCHK(c, hipMalloc(&c->d_col, sizeof(double) * 6 * c->g.colsize * c->batch * 2));
-  HIPCHK(c, zero_device(c->d_col, sizeof(double) * 6 * c->g.colsize * c->batch * 2, c->stream));
+  c->col_slots = 0;
+  // two ping-pong sets of `batch` slots; on a mesh too large for that (6.5 GB per slot at 512^3, 22 GB at
+  // 768^3) the batch shrinks to what fits in 80 % of the free memory instead of failing
+  const size_t slot = sizeof(double) * 6 * c->g.colsize;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+  const size_t fit = (size_t)(0.8 * (double)free_b) / (2 * slot);
+  if (fit < 1) return fail(c, "column scratch: one slot of %.1f GB x 2 does not fit in %.1f GB of free device memory", slot / 1e9, free_b / 1e9);
+  if ((size_t)c->batch > fit) c->batch = (int)fit;
+  HIPCHK(c, hipMalloc(&c->d_col, slot * c->batch * 2));
+  HIPCHK(c, zero_device(c->d_col, slot * c->batch * 2, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->col_slots = c->batch;
   return 0;
