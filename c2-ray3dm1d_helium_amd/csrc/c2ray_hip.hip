@@ -1593,7 +1593,15 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
             for (int tj_ = 0; tj_ < nt2; tj_++) {
               if (!cov[1][tj_]) continue;
               unsigned char *row = &mark[((size_t)tk * nt2 + tj_) * nt1];
-              for (int ti_ = 0; ti_ < nt1; ti_++) row[ti_] |= cov[0][ti_];
+              int ti_ = 0;
+              for (; ti_ + 8 <= nt1; ti_ += 8) { // eight tiles per OR
+                unsigned long long a, b_;
+                std::memcpy(&a, row + ti_, 8);
+                std::memcpy(&b_, cov[0].data() + ti_, 8);
+                a |= b_;
+                std::memcpy(row + ti_, &a, 8);
+              }
+              for (; ti_ < nt1; ti_++) row[ti_] |= cov[0][ti_];
             }
           }
         }

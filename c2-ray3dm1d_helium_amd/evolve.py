@@ -421,34 +421,56 @@ class Evolve:
         self.conv_flags: list[int] = []
         self.sum_nbox_all = 0
         self.photon_loss_all = np.zeros(NFREQ)
+        self.iteration_dump: dict | None = None
 
     # subroutine evolve3D (time,dt,restart) -- evolve.F90:78
     def evolve3D(self, time, dt, restart, material: Material, grid: GridProps, sources: SourceProps,
-                 cosmology: Cosmology | None = None):
-        if restart != 0:
-            raise NotImplementedError("restart from an iteration dump (evolve.F90:138-140) is not available yet")
+                 cosmology: Cosmology | None = None, dump: dict | None = None, dump_at=None):
+        """evolve3D(time,dt,restart) (evolve.F90:78-229).
+
+        restart != 0 continues from an iteration dump (start_from_dump + global_pass, evolve.F90:138-140):
+        `dump` is the dictionary an earlier call left in `self.iteration_dump`.  `dump_at` (an iterable of
+        iteration numbers) stands for the reference's wall-clock trigger (a dump every 15 minutes, :196-210):
+        after pass_all_sources of those iterations the dump content is taken off the device
+        (write_iteration_dump, :233-275: niter, photon_loss_all, phih_grid, phihe_grid, [phiheat], xh_av, xhe_av,
+        xh_intermed, xhe_intermed)."""
         cosmology = cosmology or Cosmology()
         e = self.engine
         e.set_step(material, grid, cosmology)
         e.set_sources(sources)
+        if restart != 0 and dump is not None and dump.get("temperature") is not None and not material.isothermal:
+            # not part of the reference's dump file: the temperature slots as the interrupted call left them, so
+            # that a non-isothermal continuation is bit-identical (the reference restarts from the last output)
+            material.temperature_grid = np.array(dump["temperature"], dtype=np.float32)
         e.upload_state(material)
-        if self.comm is None or self.comm.size == 1:
+        single = self.comm is None or self.comm.size == 1
+        if restart == 0 and not dump_at and single:
             self.niter, self.conv_flags = e.evolve3d(dt)
         else:
-            self._evolve3d_multi(dt, sources.NumSrc)
+            if restart != 0 and dump is None:
+                raise C2RayHipError("evolve3D: restart /= 0 needs the iteration dump to start from")
+            self._evolve3d_stepwise(dt, sources.NumSrc, dump if restart != 0 else None, set(dump_at or ()))
         e.download_state(material)
         r = e.download_rates()
         self.sum_nbox_all = r["sum_nbox"]
         self.photon_loss_all = r["photon_loss"]
         return self.niter
 
-    def _evolve3d_multi(self, dt, numsrc):
-        e, comm = self.engine, self.comm
+    def _evolve3d_stepwise(self, dt, numsrc, dump, dump_at):
+        e = self.engine
+        comm = self.comm if self.comm is not None and self.comm.size > 1 else None
         ncell = int(np.prod(self.mesh))
-        e.begin_step()
-        niter, conv_flag = 0, ncell
-        conv_criterion = min(int(convergence_fraction * self.mesh[0] * self.mesh[1] * self.mesh[2]), numsrc)
         self.conv_flags = []
+        if dump is None:
+            e.begin_step()
+            niter, conv_flag = 0, ncell
+        else:  # start_from_dump, then global_pass
+            e.upload_rates(dump["phih_grid"], dump["phihe_grid"], dump.get("phiheat"))
+            e.upload_iter_state(dump["xh_av"], dump["xhe_av"], dump["xh_intermed"], dump["xhe_intermed"])
+            niter = int(dump["niter"])
+            conv_flag = e.global_pass(dt)
+            self.conv_flags.append(conv_flag)
+        conv_criterion = min(int(convergence_fraction * self.mesh[0] * self.mesh[1] * self.mesh[2]), numsrc)
         while True:
             if conv_flag < conv_criterion and niter > 1:
                 e.end_step()
@@ -458,7 +480,17 @@ class Evolve:
             niter += 1
             e.set_rates_to_zero()
             if numsrc > 0:
-                comm.pass_and_allreduce(e)
+                if comm is not None:
+                    comm.pass_and_allreduce(e)
+                else:
+                    e.pass_sources(1, 1)
+                if niter in dump_at:
+                    self.iteration_dump = {"niter": niter, **e.download_rates(), **e.download_iter_state()}
+                    if not e.isothermal:
+                        tmp = Material(ndens=None, xh=np.empty(2 * ncell), xhe=np.empty(3 * ncell),
+                                       temperature_grid=np.empty(3 * ncell, dtype=np.float32), isothermal=False)
+                        e.download_state(tmp)
+                        self.iteration_dump["temperature"] = tmp.temperature_grid
             conv_flag = e.global_pass(dt)
             self.conv_flags.append(conv_flag)
         self.niter = niter

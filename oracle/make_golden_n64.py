@@ -6,6 +6,7 @@ iteration history, SHA-256 of every output array, and the ionised-fraction line 
 (the reference's own Ifront diagnostic, files_for_3D/output.F90:192-244).
 
     python oracle/make_golden_n64.py      (dev container; ~2 minutes)
+    python oracle/make_golden_n64.py 128 64,64,64,3e55 10,120,70,1e55     (a larger box, two sources: ~10 minutes)
 """
 import hashlib
 import shutil
@@ -22,6 +23,10 @@ import refrun  # noqa: E402
 
 N = 64
 SOURCES = [(32, 32, 32, 1e54)]
+if len(sys.argv) > 2:
+    N = int(sys.argv[1])
+    SOURCES = [tuple(float(x) if i == 3 else int(x) for i, x in enumerate(a.split(","))) for a in sys.argv[2:]]
+NAME = f"n{N}_heat_{len(SOURCES)}src"
 
 
 def sha(a):
@@ -30,7 +35,7 @@ def sha(a):
 
 def main():
     subprocess.run([str(HERE / "ref_build.sh"), str(N)], check=True)
-    run = refrun.run_reference(N, SOURCES, isothermal=False, steps_per_slice=1, name="golden_N64_heat_1src")
+    run = refrun.run_reference(N, SOURCES, isothermal=False, steps_per_slice=1, name="golden_" + NAME)
     conv = refrun.parse_log(run)
     out = {"ncalls": np.int32(len(conv))}
     for call in range(1, len(conv) + 1):
@@ -51,13 +56,14 @@ def main():
         for k in ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av"]:
             out[p + "sha_" + k] = np.array(sha(tout[k]))
         xh1 = tout["xh"][N ** 3:].reshape(N, N, N, order="F")
-        out[p + "xHII_line"] = xh1[:, 31, 31].copy()
-        out[p + "T_line"] = tout["temperature"][:N ** 3].reshape(N, N, N, order="F")[:, 31, 31].copy()
+        j0, k0 = SOURCES[0][1] - 1, SOURCES[0][2] - 1   # the line through the first source
+        out[p + "xHII_line"] = xh1[:, j0, k0].copy()
+        out[p + "T_line"] = tout["temperature"][:N ** 3].reshape(N, N, N, order="F")[:, j0, k0].copy()
         out[p + "sum_nbox"] = tout["sum_nbox_all"]
         out[p + "reccoef_after"] = tout["reccoef"]
-    np.savez_compressed(ROOT / "tests" / "golden" / "n64_heat_1src.npz", **out)
+    np.savez_compressed(ROOT / "tests" / "golden" / (NAME + ".npz"), **out)
     shutil.rmtree(run)  # 300 MB of tap dumps: scratch
-    print("calls", [len(c) for c in conv], "fixture", (ROOT / "tests/golden/n64_heat_1src.npz").stat().st_size, "bytes")
+    print("calls", [len(c) for c in conv], "fixture", (ROOT / "tests/golden" / (NAME + ".npz")).stat().st_size, "bytes")
 
 
 if __name__ == "__main__":

@@ -289,14 +289,16 @@ def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
     e.close()
 
 
-def test_config2_64cube_point_source_vs_reference(pkg, tables, gold):
+@pytest.mark.parametrize("fixture", ["n64_heat_1src.npz", "n128_heat_2src.npz"])
+def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     """BASELINE configs[1]: 64^3 uniform density, one point source (1e54 photons/s, 5e4 K black body),
     heating on, four consecutive evolve3D calls (83 outer iterations) chained exactly as the
-    reference's driver chains them.  Every output array has the SHA-256 of the reference's, the
-    iteration history is the same, and so is the ionisation front along the line through the source."""
+    reference's driver chains them -- and the same at 128^3 with two sources.  Every output array has the
+    SHA-256 of the reference's, the iteration history is the same, and so is the ionisation front along
+    the line through the (first) source."""
     import hashlib
-    z = gold("n64_heat_1src.npz")
-    n = 64
+    z = gold(fixture)
+    n = int(z["c1_mesh"][0])
     nc = n ** 3
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     xh = np.repeat(z["c1_xh_uniform"], nc)
@@ -318,15 +320,15 @@ def test_config2_64cube_point_source_vs_reference(pkg, tables, gold):
         got = {"xh": xh, "xhe": xhe, "temperature": temp, **ev.rates, **ev.iter_state}
         for k in ["xh", "xhe", "temperature", "phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av"]:
             assert sha(got[k]) == str(g("sha_" + k)), (call, k)
-        line = xh[nc:].reshape(n, n, n, order="F")[:, 31, 31]
+        i0, j0, k0 = (int(x) - 1 for x in g("srcpos").reshape(-1, 3)[0])
+        line = xh[nc:].reshape(n, n, n, order="F")[:, j0, k0]
         assert np.array_equal(line, g("xHII_line"))
         # I-front radius (x_HII = 0.5 crossing on the +x side of the source), in cells
-        i0 = 31
         r = next((i - i0 for i in range(i0, n) if line[i] < 0.5), None)
         log[f"call{call}"] = dict(niter=niter, ifront_cells=r, xHII_at_source=float(line[i0]))
         assert np.array_equal(ev.engine.get_reccoef(), g("reccoef_after"))
         assert ev.sum_nbox_all == int(g("sum_nbox")[0])
-    dump(log, "config2_n64.json")
+    dump(log, f"config2_{fixture[:-4]}.json")
 
 
 @pytest.mark.parametrize("mesh,iso", [((12, 16, 20), True), ((20, 12, 14), False)])
@@ -715,3 +717,26 @@ def test_no_sources_runs_501_global_passes(pkg, orc, otables, tables):
     it = ev.iter_state
     assert np.array_equal(it["xh_intermed"], s.xh_intermed) and it["xh_intermed"][nc:].mean() < 0.5 * x.mean()
     assert not np.any(ev.rates["phih_grid"])
+
+
+def test_evolve3d_restart_argument(pkg, tables, gold):
+    """evolve3D(time,dt,restart) with restart /= 0 in the Python mirror: a first call leaves an iteration dump
+    after pass_all_sources of iteration 5 (standing for the 15-minute trigger, evolve.F90:196-210); a second
+    Evolve object on a fresh context restarts from it (start_from_dump + global_pass, :138-140) and ends with
+    the bits and the iteration count of the reference's uninterrupted call."""
+    i, o = tap_case(gold("tap_N16_heat_3src.npz"), 1)
+    mesh, mat, grid, src, cosmo = make_inputs(pkg, i)
+    dt = float(i["dt"][0])
+    ev = pkg.Evolve(mesh, tables, device=0)
+    n1 = ev.evolve3D(0.0, dt, 0, mat, grid, src, cosmo, dump_at=[5])
+    assert n1 == len(o["conv_flags"]) and np.array_equal(mat.xh, o["xh"])
+    d = ev.iteration_dump
+    assert d is not None and d["niter"] == 5
+    mesh, mat2, grid, src, cosmo = make_inputs(pkg, i)           # the state at the start of the time step
+    ev2 = pkg.Evolve(mesh, tables, device=0)
+    n2 = ev2.evolve3D(0.0, dt, 1, mat2, grid, src, cosmo, dump=d)
+    assert n2 == len(o["conv_flags"])
+    # the restarted call re-runs the global pass of iteration 5 and then iterations 6..: same history from there
+    assert ev2.conv_flags == [int(x) for x in o["conv_flags"]][4:]
+    assert np.array_equal(mat2.xh, o["xh"]) and np.array_equal(mat2.xhe, o["xhe"])
+    assert np.array_equal(mat2.temperature_grid, o["temperature"])
