@@ -180,9 +180,9 @@ def main():
     def step():
         e.set_rates_to_zero()
         if comm is not None:
-            comm.pass_and_allreduce(e)   # the sum over ranks overlaps the pass slab by slab (parallel.py)
-        else:
-            e.pass_sources(1, 1)
+            # pass, sum over ranks and global pass overlapped slab by slab (parallel.py)
+            return comm.pass_allreduce_chemistry(e, dt)
+        e.pass_sources(1, 1)
         return e.global_pass(dt)
 
     def barrier():

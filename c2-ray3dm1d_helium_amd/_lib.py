@@ -65,6 +65,8 @@ SYMBOLS = {
     "c2r_pass_sources_end": (C.c_int, [C.c_void_p]),
     "c2r_do_source": (C.c_int, [C.c_void_p, C.c_int]),
     "c2r_global_pass": (C.c_int, [C.c_void_p, C.c_double, _ip]),
+    "c2r_global_pass_cells": (C.c_int, [C.c_void_p, C.c_double, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "c2r_global_pass_finish": (C.c_int, [C.c_void_p, _ip]),
     "c2r_end_step": (C.c_int, [C.c_void_p]),
     "c2r_download_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
     "c2r_get_loss": (C.c_int, [C.c_void_p, _dp, _ip]),

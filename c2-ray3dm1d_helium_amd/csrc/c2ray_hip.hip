@@ -465,11 +465,11 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
-            const float *__restrict__ clumping_grid) {
+            const float *__restrict__ clumping_grid, size_t q_first, size_t q_end) {
   const size_t nc = g.ncell;
-  const size_t q = (size_t)blockIdx.x * C2R_CHEM_BLOCK + threadIdx.x;
+  const size_t q = q_first + (size_t)blockIdx.x * C2R_CHEM_BLOCK + threadIdx.x;
   int notconv = 0;
-  if (q < nc) {
+  if (q < q_end) {
     // clumping_point for type_of_clumping = 5 (evolve_point.F90:483-484; REAL(4) grid)
     const double clumping = clumping_grid ? (double)clumping_grid[q] : sc.clumping;
     IonStates ion;
@@ -773,11 +773,14 @@ struct c2r_ctx {
   // second stream for the rates kernels: the (latency-bound) column sweep of batch n+1 runs beside
   // the (ALU-bound) rates kernel of batch n; two scratch sets ping-pong between them
   hipStream_t stream2 = nullptr;
+  hipStream_t stream3 = nullptr;    // takes every other slab of a cut rates launch (kernel tails overlap)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_sweep_done[2] = {nullptr, nullptr}, ev_rates_done[2] = {nullptr, nullptr};
   bool set_busy[2] = {false, false};
   std::vector<hipEvent_t> ev_pool; // timing events, grown on demand
   size_t ev_used = 0;
 
+  int chem_pieces = 0;              // pieces of the open global pass (c2r_global_pass_cells)
   // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
   bool pass_open = false;
   int pass_slabs = 0;
@@ -876,6 +879,9 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     CR(hipDeviceGetStreamPriorityRange(&lo, &hi));
     CR(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
     CR(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+    CR(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo));
+    CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
   for (int i = 0; i < 2; i++) {
     CR(hipEventCreateWithFlags(&c->ev_sweep_done[i], hipEventDisableTiming));
@@ -953,6 +959,9 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
     if (c->ev_rates_done[i]) (void)hipEventDestroy(c->ev_rates_done[i]);
   }
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1616,12 +1625,20 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       }
     }
 #define C2R_LAUNCH_RATES(H, M)                                                                               \
-  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), 0, c->stream2, g, ba, sc, c->d_ndens,  \
+  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), 0, st_, g, ba, sc, c->d_ndens,  \
                      c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates, d_tiles, base_)
     const bool last_batch = b0 + c->batch >= mine.size();
     const int pieces = (last_batch && ns_eff > 0) ? ns_eff : 1;
     const int per_layer = nt1 * nt2;
+    // slabs alternate between two streams so that the thin tail of one launch overlaps the start of the
+    // next; the third stream is forked from (and joined back into) the rates stream, which carries the
+    // dependencies on the sweep, on earlier batches and on the tile-list copy
+    if (pieces > 1) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, c->stream2));
+      HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+    }
     for (int piece = 0; piece < pieces; piece++) {
+      hipStream_t st_ = (pieces > 1 && (piece & 1)) ? c->stream3 : c->stream2;
       // tiles of the layers [l0, l1): a contiguous range of tile ids, hence of the (sorted) list too
       const int l0 = pieces == 1 ? 0 : c->slab_k[piece] / 4;
       const int l1 = pieces == 1 ? nt3 : (c->slab_k[piece + 1] + 3) / 4;
@@ -1641,7 +1658,11 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           if (multi) C2R_LAUNCH_RATES(true, true); else C2R_LAUNCH_RATES(true, false);
         }
       }
-      if (last_batch && ns_eff > 0) HIPCHK(c, hipEventRecord(c->ev_slab[piece], c->stream2));
+      if (last_batch && ns_eff > 0) HIPCHK(c, hipEventRecord(c->ev_slab[piece], st_));
+    }
+    if (pieces > 1) {
+      HIPCHK(c, hipEventRecord(c->ev_join, c->stream3));
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_join, 0));
     }
 #undef C2R_LAUNCH_RATES
     HIPCHK(c, hipGetLastError());
@@ -1737,24 +1758,51 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
   return pass_list(c, std::vector<int>{ns});
 }
 
-extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
+// The global pass over a range of cells, queued behind `after_event` (an event of another stream, e.g. the
+// one on which the caller's sum over ranks of these cells completes; may be null).  A range starting at
+// cell 0 opens a pass (zeroes the non-converged count); c2r_global_pass_finish closes it.
+extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, size_t ncells, void *after_event) {
   if (!c) return 1;
-  if (check_ready(c, "c2r_global_pass")) return 1;
+  if (check_ready(c, "c2r_global_pass_cells")) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   const Grid g = c->g;
+  if (first_cell > g.ncell || ncells > g.ncell - first_cell) return fail(c, "c2r_global_pass_cells: range outside the mesh");
   const StepScalars sc = scalars(c);
-  const int nblk = (int)((g.ncell + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
-  HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
-  if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (first_cell == 0) {
+    HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    // the second stream takes every other piece: it must see the zeroed counter (and everything before)
+    HIPCHK(c, hipEventRecord(c->ev_sweep_done[0], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
+    c->tm.chem_launches = 0;
+    c->chem_pieces = 0;
+  }
+  // Pieces alternate between the two streams: the cells of a piece need very different numbers of
+  // do_chemistry iterations, so every launch ends in a long thin tail; on alternating streams the next
+  // piece fills the chip while the previous one drains.
+  hipStream_t st = (c->chem_pieces++ & 1) ? c->stream2 : c->stream;
+  if (after_event) HIPCHK(c, hipStreamWaitEvent(st, static_cast<hipEvent_t>(after_event), 0));
+  if (ncells == 0) return 0;
+  const int nblk = (int)((ncells + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
   if (c->isothermal)
-    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
+    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
-                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr);
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first_cell, first_cell + ncells);
   else
-    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, c->stream, g, sc, dt, c->d_ndens, c->d_xh,
+    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
-                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr);
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first_cell, first_cell + ncells);
   HIPCHK(c, hipGetLastError());
+  c->tm.chem_launches++;
+  return 0;
+}
+
+extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  // join the second stream, then read the count on the first
+  HIPCHK(c, hipEventRecord(c->ev_rates_done[0], c->stream2));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[0], 0));
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1762,10 +1810,15 @@ extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));
     c->tm.chem_ms = ms;
-    c->tm.chem_launches = 1;
   }
   if (conv_flag) *conv_flag = *c->h_conv;
   return 0;
+}
+
+extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
+  if (!c) return 1;
+  if (c2r_global_pass_cells(c, dt, 0, c->g.ncell, nullptr)) return 1;
+  return c2r_global_pass_finish(c, conv_flag);
 }
 
 extern "C" int c2r_evolve3d(c2r_ctx *c, double dt, int *niter_out, int *conv_flags_out, int cap) {

@@ -301,6 +301,16 @@ class HipEngine:
         self._chk(self.lib.c2r_global_pass(self.h, float(dt), C.byref(cf)))
         return cf.value
 
+    def global_pass_cells(self, dt, first_cell, ncells, after_event=None):
+        """Queue the chemistry of a range of cells, after a hipEvent_t handle (int) of another stream."""
+        self._chk(self.lib.c2r_global_pass_cells(self.h, float(dt), int(first_cell), int(ncells),
+                                                 C.c_void_p(after_event) if after_event else None))
+
+    def global_pass_finish(self):
+        conv = C.c_int(0)
+        self._chk(self.lib.c2r_global_pass_finish(self.h, C.byref(conv)))
+        return int(conv.value)
+
     def end_step(self):
         self._chk(self.lib.c2r_end_step(self.h))
 
@@ -479,6 +489,11 @@ class Evolve:
                 break
             niter += 1
             e.set_rates_to_zero()
+            fused = comm is not None and numsrc > 0 and niter not in dump_at and callable(getattr(comm, "pass_allreduce_chemistry", None))
+            if fused:   # pass, sum over ranks and global pass overlapped slab by slab (parallel.py)
+                conv_flag = comm.pass_allreduce_chemistry(e, dt)
+                self.conv_flags.append(conv_flag)
+                continue
             if numsrc > 0:
                 if comm is not None:
                     comm.pass_and_allreduce(e)

@@ -204,6 +204,21 @@ module c2ray_hip
        integer(c_int), value :: ns
      end function c2r_do_source
 
+     integer(c_int) function c2r_global_pass_cells(ctx, dt, first_cell, ncells, after_event) &
+          bind(C, name="c2r_global_pass_cells")
+       import :: c_int, c_ptr, c_double, c_size_t
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_size_t), value :: first_cell, ncells
+       type(c_ptr), value :: after_event          ! hipEvent_t or c_null_ptr
+     end function c2r_global_pass_cells
+
+     integer(c_int) function c2r_global_pass_finish(ctx, conv_flag) bind(C, name="c2r_global_pass_finish")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: conv_flag
+     end function c2r_global_pass_finish
+
      integer(c_int) function c2r_global_pass(ctx, dt, conv_flag) bind(C, name="c2r_global_pass")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

@@ -7,11 +7,13 @@ with six MPI_ALLREDUCE calls.  Here that is ONE fp64 SUM all-reduce over the con
 [phih | phihe(0) | phihe(1) | phiheat | photon_loss(1:47) | sum_nbox] through torch.distributed
 (backend "nccl" == RCCL over xGMI on the GPUs; "gloo" in the CPU tests).
 
-On the GPUs the sum is pipelined with the pass itself (`pass_and_allreduce`): the rates launch of a rank's last
-batch is cut into slabs of k-planes, and the all-reduce of slab s (3 or 4 component ranges of the buffer) runs
-on RCCL's stream while the device computes the rates of slabs s+1...  xGMI is point to point -- two ranks share
-one link, ~50 GB/s per direction -- so 403 MB per iteration at 256^3 would otherwise cost ~10 ms next to a
-37 ms iteration; pipelined, only the last slab's share is exposed.
+On the GPUs the sum is pipelined with the pass before it and the global pass after it
+(`pass_allreduce_chemistry`): the rates launch of a rank's last batch is cut into slabs of k-planes, the
+all-reduce of slab s (3 or 4 component ranges of the buffer) runs on RCCL's stream while the device computes
+the rates of slabs s+1..., and the chemistry of slab s is queued behind the event that marks its sum complete,
+i.e. it runs while later slabs are still on the wire.  xGMI is point to point -- two ranks share one link,
+~50 GB/s per direction -- so 403 MB per iteration at 256^3 would otherwise cost ~10 ms next to a 34 ms
+iteration.  Cutting costs ~0.2 ms per slab (kernel tails, partly hidden by alternating streams); default 4.
 """
 from __future__ import annotations
 
@@ -43,7 +45,7 @@ class TorchComm:
             return self.allreduce_rates(engine)
         if nslab is None:
             import os
-            nslab = int(os.environ.get("C2R_ALLREDUCE_SLABS", "6"))
+            nslab = int(os.environ.get("C2R_ALLREDUCE_SLABS", "4"))
         buf = engine.rates_buffer()
         nc = (buf.numel() - 48) // 4
         ncomp = 3 if getattr(engine, "isothermal", False) else 4   # phiheat stays zero in isothermal runs
@@ -62,6 +64,47 @@ class TorchComm:
             import torch
             torch.cuda.current_stream(buf.device).synchronize()
         engine.rates_reduced()
+
+
+    def pass_allreduce_chemistry(self, engine, dt, nslab=None):
+        """One outer iteration's pass_all_sources + mpi_accumulate_grid_quantities + global_pass with all three
+        overlapped: slab s is all-reduced while the rates of slab s+1 are computed, and its chemistry runs as soon
+        as its sum is complete, i.e. while later slabs are still on the wire.  Returns the non-converged count."""
+        if not (hasattr(engine, "pass_sources_begin") and hasattr(engine, "global_pass_cells")):
+            self.pass_and_allreduce(engine, nslab)
+            return engine.global_pass(dt)
+        import os
+        import torch
+        if nslab is None:
+            nslab = int(os.environ.get("C2R_ALLREDUCE_SLABS", "4"))
+        buf = engine.rates_buffer()
+        nc = (buf.numel() - 48) // 4
+        ncomp = 3 if getattr(engine, "isothermal", False) else 4
+        n = engine.pass_sources_begin(1 + self.rank, self.size, nslab)
+        slabs = []
+        for s in range(n):
+            c0, cnt = engine.pass_wait_slab(s)
+            works = [self.dist.all_reduce(buf[comp * nc + c0: comp * nc + c0 + cnt], op=self.dist.ReduceOp.SUM,
+                                          group=self.group, async_op=True) for comp in range(ncomp)]
+            slabs.append((c0, cnt, works))
+        engine.pass_sources_end()
+        tail = self.dist.all_reduce(buf[4 * nc:], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        events = []
+        for c0, cnt, works in slabs:
+            for w in works:
+                w.wait()                       # torch's current stream now waits for this slab's sum
+            handle = None
+            if buf.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()                    # ... and the library's stream waits for that point
+                events.append(ev)
+                handle = ev.cuda_event
+            engine.global_pass_cells(dt, c0, cnt, handle)
+        tail.wait()
+        if buf.is_cuda:
+            torch.cuda.current_stream(buf.device).synchronize()
+        engine.rates_reduced()
+        return engine.global_pass_finish()
 
 
 class SingleComm:

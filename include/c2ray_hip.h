@@ -152,6 +152,13 @@ int c2r_pass_sources_end(c2r_ctx *ctx);
  * and add its contribution to the rate grids, photon_loss(1) and sum_nbox. */
 int c2r_do_source(c2r_ctx *ctx, int ns);
 int c2r_global_pass(c2r_ctx *ctx, double dt, int *conv_flag);
+/* The same pass in pieces, for a multi-rank host that applies the rates of a slab of cells as soon as their
+ * sum over ranks is complete: c2r_global_pass_cells queues evolve0D_global for cells [first_cell, first_cell +
+ * ncells) on the library's stream, after `after_event` (a hipEvent_t recorded on the stream that finishes the
+ * sum, or NULL); the piece starting at cell 0 opens a pass.  c2r_global_pass_finish waits for all pieces and
+ * returns the non-converged count of the pass. */
+int c2r_global_pass_cells(c2r_ctx *ctx, double dt, size_t first_cell, size_t ncells, void *after_event);
+int c2r_global_pass_finish(c2r_ctx *ctx, int *conv_flag);
 int c2r_end_step(c2r_ctx *ctx);
 
 /* evolve_data: phih_grid, phihe_grid(:,:,:,0:1), phiheat; photonstatistics: photon_loss(1:47)

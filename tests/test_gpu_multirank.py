@@ -33,6 +33,7 @@ def _worker(rank, world, port, q, pipelined=True):
             e.pass_sources(1 + comm.rank, comm.size)
             comm.allreduce_rates(e)
         comm.pass_and_allreduce = plain
+        comm.pass_allreduce_chemistry = None
     ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), device=0, comm=comm)
     n = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
     if rank == 0:
@@ -59,8 +60,9 @@ def test_two_ranks_on_one_gpu(pkg, gold):
     _, o = tap_case(gold("tap_N16_heat_3src.npz"), 2)
     port = 29600 + (os.getpid() % 2000)
     res = _run_two_ranks(True, port)
-    # the slab-pipelined sum (rates of slab s+1 computed while slab s is reduced) changes no bit against the
-    # whole-buffer all-reduce after the pass: two ranks, a + b == b + a
+    # the slab-pipelined iteration (rates of slab s+1 computed while slab s is reduced, chemistry of slab s as
+    # soon as its sum is complete) changes no bit against pass -> whole-buffer all-reduce -> global pass:
+    # two ranks, a + b == b + a
     plain = _run_two_ranks(False, port + 1)
     assert res["niter"] == plain["niter"] and res["nbox"] == plain["nbox"] and res["loss"] == plain["loss"]
     for k in ("xh", "temp", "phih"):
