@@ -450,18 +450,25 @@ C2R_HD Ricotti ricotti_parameters(double i_state) {
   return R;
 }
 
+// what one photo_lookuptable + heat_lookuptable pair of calls returns for one SED (before the sums of
+// radiation_photoionrates.f90:178-262 put them together)
+struct SedAcc {
+  double photo_HI, photo_HeI, photo_HeII, photo_out; // photo_lookuptable
+  double f_heat, f_ion_HI, f_ion_HeI;                // heat_lookuptable
+};
+
 // radiation_photoionrates.f90:108-277 photoion_rates with its callees photo_lookuptable (:331-464),
 // heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands.
 // Band-local quantities are computed in the reference's order; sums over bands run b = 1..bb_upper
 // as in the reference.  HEAT selects the non-isothermal path.
 template <bool HEAT>
-C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
-                           const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
-                           double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                           double NFlux, const Ricotti &ric, PhotoOut &o) {
+C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
+                      const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
+                      double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
+                      double NFlux, const Ricotti &ric, SedAcc &o) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
-  o.heat = 0.0;
   o.photo_out = 0.0;
+  o.f_heat = o.f_ion_HI = o.f_ion_HeI = 0.0;
   if (!(NFlux > 0.0)) return;
   const Recip rvol = make_recip(vol);
   const double cell_HI = cout_HI - cin_HI;
@@ -472,8 +479,7 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
   double df_ion_HI = 0.0, df_ion_HeI = 0.0;
   const double *y1R = ric.y1R, *y2R = ric.y2R;
 
-  const int nb = bd.bb_upper;
-  for (int b = 0; b < nb; b++) { // b is 0-based here; reference band = b+1
+  for (int b = blo; b < bhi; b++) { // b is 0-based here; reference band = b+1
     const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
     const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
     const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
@@ -611,10 +617,32 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
     }
   }
   if (HEAT) {
+    o.f_heat = f_heat;
+    o.f_ion_HI = f_ion_HI;
+    o.f_ion_HeI = f_ion_HeI;
+  }
+}
+
+
+// photoion_rates for a source with the black-body SED only
+template <bool HEAT>
+C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
+                           const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
+                           double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
+                           double NFlux, const Ricotti &ric, PhotoOut &o) {
+  SedAcc a;
+  sed_rates<HEAT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
+                  cin_HeII, cout_HeII, vol, NFlux, ric, a);
+  o.photo_HI = a.photo_HI;
+  o.photo_HeI = a.photo_HeI;
+  o.photo_HeII = a.photo_HeII;
+  o.photo_out = a.photo_out;
+  o.heat = 0.0;
+  if (HEAT) {
     // phi = phi + heat_lookuptable(...) (:247-252): adds to photo_cell_HI / HeI and heat
-    o.heat = f_heat;
-    o.photo_HI = o.photo_HI + f_ion_HI / (ion_freq_HI * hplanck);
-    o.photo_HeI = o.photo_HeI + f_ion_HeI / (ion_freq_HeI * hplanck);
+    o.heat = a.f_heat;
+    o.photo_HI = o.photo_HI + a.f_ion_HI / (ion_freq_HI * hplanck);
+    o.photo_HeI = o.photo_HeI + a.f_ion_HeI / (ion_freq_HeI * hplanck);
   }
 }
 
@@ -636,172 +664,35 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
+  // one band loop per SED over its own band range, like the reference's lookuptable calls (the tau
+  // positions of a band shared by two SEDs are evaluated twice: ranges rarely overlap -- BB 1..33,
+  // PL and QPL 38..47 in the nominal set-up -- and one loop at a time needs far fewer registers)
+  SedAcc a[NSED];
   bool act[NSED];
-  int blo = NFREQ, bhi = 0;
   for (int s = 0; s < NSED; s++) {
     act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
-    if (act[s]) { blo = ss.lo[s] < blo ? ss.lo[s] : blo; bhi = ss.hi[s] > bhi ? ss.hi[s] : bhi; }
-  }
-  if (bhi <= blo) return;
-  const Recip rvol = make_recip(vol);
-  const double cell_HI = cout_HI - cin_HI;
-  const double cell_HeI = cout_HeI - cin_HeI;
-  const double cell_HeII = cout_HeII - cin_HeII;
-  double P_HI[NSED] = {0, 0, 0}, P_HeI[NSED] = {0, 0, 0}, P_HeII[NSED] = {0, 0, 0}, P_out[NSED] = {0, 0, 0};
-  double f_heat[NSED] = {0, 0, 0}, f_ion_HI[NSED] = {0, 0, 0}, f_ion_HeI[NSED] = {0, 0, 0};
-  double df_ion_HI[NSED] = {0, 0, 0}, df_ion_HeI[NSED] = {0, 0, 0};
-  const double *y1R = ric.y1R, *y2R = ric.y2R;
-  for (int b = blo; b < bhi; b++) {
-    bool any = false;
-    for (int s = 0; s < NSED; s++) any = any || (act[s] && b >= ss.lo[s] && b < ss.hi[s]);
-    if (!any) continue;
-    const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
-    const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
-    const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
-    const TauPos pin = tau_table_position(tau_in);
-    const double dtau = tau_out - tau_in;
-    const bool thick = fabs(dtau) > tau_photo_limit;
-    const bool hthick = fabs(dtau) > tau_heat_limit;
-    TauPos pout;
-    if (thick || (HEAT && hthick)) pout = tau_table_position(tau_out);
-    else { pout.ipos = 0; pout.residual = 0.0; }
-    double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
-    if (b >= NB1 && b < NB1 + NB2) {
-      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI);
-      sc_HI = sHI * cell_HI * forscaleing;
-      sc_HeI = sHeI * cell_HeI * forscaleing;
-    } else if (b >= NB1 + NB2) {
-      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
-      sc_HI = cell_HI * sHI * forscaleing;
-      sc_HeI = cell_HeI * sHeI * forscaleing;
-      sc_HeII = cell_HeII * sHeII * forscaleing;
-    }
-    for (int s = 0; s < NSED; s++) {
-      if (!(act[s] && b >= ss.lo[s] && b < ss.hi[s])) continue;
-      const double NF = NFlux[s];
-      {
-        const double *tk = ss.photo_thick[s] + (size_t)b * NTAUP;
-        double phi_in = NF * read_table(tk, pin);
-        double phi_out, phi_all;
-        if (thick) {
-          phi_out = NF * read_table(tk, pout);
-          phi_all = phi_in - phi_out;
-        } else {
-          phi_all = NF * dtau * read_table(ss.photo_thin[s] + (size_t)b * NTAUP, pin);
-          phi_out = phi_in - phi_all;
-        }
-        P_out[s] = P_out[s] + phi_out;
-        if (b < NB1) {
-          P_HI[s] = P_HI[s] + div_recip(phi_all, rvol);
-        } else if (b < NB1 + NB2) {
-          P_HI[s] = P_HI[s] + div_recip(sc_HI * phi_all, rvol);
-          P_HeI[s] = P_HeI[s] + div_recip(sc_HeI * phi_all, rvol);
-        } else {
-          P_HI[s] = P_HI[s] + div_recip(sc_HI * phi_all, rvol);
-          P_HeI[s] = P_HeI[s] + div_recip(sc_HeI * phi_all, rvol);
-          P_HeII[s] = P_HeII[s] + div_recip(sc_HeII * phi_all, rvol);
-        }
-      }
-      if (HEAT) {
-        double df_heat;
-        const double *HT = ss.heat_thick[s], *HN = ss.heat_thin[s];
-        if (b < NB1) {
-          const double *tk = HT + (size_t)b * NTAUP;
-          double in_HI = NF * read_table(tk, pin);
-          double h_HI;
-          if (hthick) {
-            double out_HI = NF * read_table(tk, pout);
-            h_HI = div_recip(in_HI - out_HI, rvol);
-          } else {
-            h_HI = NF * (cell_HI * sHI) * read_table(HN + (size_t)b * NTAUP, pin);
-            h_HI = div_recip(h_HI, rvol);
-          }
-          df_heat = h_HI;
-        } else if (b < NB1 + NB2) {
-          const int cH = 2 * (b + 1) - NB1 - 1 - 1;
-          const double *tkH = HT + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP;
-          double in_HI = NF * read_table(tkH, pin);
-          double in_HeI = NF * read_table(tkHe, pin);
-          double h_HI, h_HeI;
-          if (hthick) {
-            double out_HI = NF * read_table(tkH, pout);
-            h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
-            double out_HeI = NF * read_table(tkHe, pout);
-            h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
-          } else {
-            const double *tnH = HN + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
-            h_HI = NF * (cell_HI * sHI) * read_table(tnH, pin);
-            h_HI = div_recip(h_HI, rvol);
-            h_HeI = NF * (cell_HeI * sHeI) * read_table(tnHe, pin);
-            h_HeI = div_recip(h_HeI, rvol);
-          }
-          df_heat = h_HI + h_HeI;
-          const int q = b - 1;
-          double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI;
-          double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
-          double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
-          double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
-          df_ion_HeI[s] = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
-          df_ion_HI[s] = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
-          df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
-        } else {
-          const int cH = 3 * (b + 1) - NB2 - NB1 * 2 - 2 - 1;
-          const double *tkH = HT + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP, *tkHe2 = tkHe + NTAUP;
-          double in_HI = NF * read_table(tkH, pin);
-          double in_HeI = NF * read_table(tkHe, pin);
-          double in_HeII = NF * read_table(tkHe2, pin);
-          double h_HI, h_HeI, h_HeII;
-          if (hthick) {
-            double out_HI = NF * read_table(tkH, pout);
-            h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
-            double out_HeI = NF * read_table(tkHe, pout);
-            h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
-            double out_HeII = NF * read_table(tkHe2, pout);
-            h_HeII = div_recip(sc_HeII * (in_HeII - out_HeII), rvol);
-          } else {
-            const double *tnH = HN + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
-            h_HI = NF * (cell_HI * sHI) * read_table(tnH, pin);
-            h_HI = div_recip(h_HI, rvol);
-            h_HeI = NF * (cell_HeI * sHeI) * read_table(tnHe, pin);
-            h_HeI = div_recip(h_HeI, rvol);
-            h_HeII = NF * (cell_HeII * sHeII) * read_table(tnHe2, pin);
-            h_HeII = div_recip(h_HeII, rvol);
-          }
-          df_heat = h_HI + h_HeI + h_HeII;
-          const int q = b - 1;
-          double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI + bd.f1ion_HeII[q] * h_HeII;
-          double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
-          double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
-          double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
-          df_ion_HeI[s] = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
-          df_ion_HI[s] = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
-          df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
-        }
-        f_heat[s] = f_heat[s] + df_heat;
-        f_ion_HI[s] = f_ion_HI[s] + df_ion_HI[s];
-        f_ion_HeI[s] = f_ion_HeI[s] + df_ion_HeI[s];
-      }
-    }
+    if (act[s])
+      sed_rates<HEAT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
+                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s]);
   }
   // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
   for (int s = 0; s < NSED; s++) {
     if (!act[s]) continue;
-    o.photo_HI = o.photo_HI + P_HI[s];
-    o.photo_HeI = o.photo_HeI + P_HeI[s];
-    o.photo_HeII = o.photo_HeII + P_HeII[s];
-    o.photo_out = o.photo_out + P_out[s];
+    o.photo_HI = o.photo_HI + a[s].photo_HI;
+    o.photo_HeI = o.photo_HeI + a[s].photo_HeI;
+    o.photo_HeII = o.photo_HeII + a[s].photo_HeII;
+    o.photo_out = o.photo_out + a[s].photo_out;
   }
   if (HEAT) {
     for (int s = 0; s < NSED; s++) {
       if (!act[s]) continue;
-      o.heat = o.heat + f_heat[s];
-      o.photo_HI = o.photo_HI + f_ion_HI[s] / (ion_freq_HI * hplanck);
-      o.photo_HeI = o.photo_HeI + f_ion_HeI[s] / (ion_freq_HeI * hplanck);
+      o.heat = o.heat + a[s].f_heat;
+      o.photo_HI = o.photo_HI + a[s].f_ion_HI / (ion_freq_HI * hplanck);
+      o.photo_HeI = o.photo_HeI + a[s].f_ion_HeI / (ion_freq_HeI * hplanck);
     }
   }
 }
 
-// photo_out of all SEDs (boundary photon loss), one table position per band as in photo_out_only
 C2R_HD double photo_out_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                               double cout_HeI, double cin_HeII, double cout_HeII, const double *NFlux) {
   double total = 0.0;

@@ -7,6 +7,11 @@ On one GPU this plays rank `--rank` of `--ranks`: it sweeps sources rank+1, rank
 ranks' rate contributions are missing, so the ionisation history is that of a 1/ranks-luminosity run --
 fine for timing the per-GPU work of a sharded run).  With --ranks 1 it is the complete problem.
 
+--config5 switches to BASELINE configs[4]'s shape: 512^3, 10^4 sources, heating on, and the three SEDs of the
+-DPL -DQUASARS build (every third source gets a power-law component, every fifth a quasar-like one), with
+the photo-ionisation and heating tables integrated on the device (c2r_build_tables) from
+tests/golden/sed_setup.npz.
+
 Not the headline bench (bench.py); prints one JSON line with per-phase times.
 """
 from __future__ import annotations
@@ -55,12 +60,30 @@ def main():
     ap.add_argument("--max-iter", type=int, default=40)
     ap.add_argument("--dt-years", type=float, default=1.0e7)
     ap.add_argument("--heating", action="store_true")
+    ap.add_argument("--config5", action="store_true")
+    ap.add_argument("--pl", action="store_true", help="the SEDs, heating and device-built tables of --config5 at --mesh / --sources")
     a = ap.parse_args()
     pkg = ge.load_package()
+    if a.config5:
+        a.mesh, a.sources = 512, 10000
+    if a.config5 or a.pl:
+        a.config5 = a.heating = True
     n = a.mesh
     mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating)
+    tables = pkg.RadiationTables.load()
+    if a.config5:
+        gold = ROOT / "tests" / "golden"
+        tables.add_sed_file(gold / "rad_tables_pl_qpl.npz")   # band ranges (the tables themselves are rebuilt)
+        with np.load(gold / "sed_setup.npz") as z:
+            tables.setup = {k: z[k] for k in z.files}
+        tables.build_on_device = True
+        idx = np.arange(a.sources)
+        src.NormFluxPL = np.where(idx % 3 == 0, 0.3 * src.NormFlux, 0.0)
+        src.NormFluxQPL = np.where(idx % 5 == 0, 0.5 * src.NormFlux, 0.0)
     e = pkg.HipEngine((n, n, n), 0)
-    e.set_tables(pkg.RadiationTables.load())
+    t_tab = time.perf_counter()
+    e.set_tables(tables)
+    t_tab = time.perf_counter() - t_tab
     e.set_step(mat, grid, cosmo)
     e.set_sources(src)
     e.upload_state(mat)
@@ -87,7 +110,8 @@ def main():
                      "rates_launches": tm.rates_launches, "nonconv": int(conv), "sum_nbox": int(e.get_loss()[1])})
     wall = time.perf_counter() - t_all
     swept = sum(h["cells_swept"] for h in hist)
-    out = {"workload": f"configs[3]-like: {n}^3 log-normal density, {a.sources} sources, rank {a.rank} of {a.ranks} "
+    out = {"tables_s": t_tab,
+           "workload": f"configs[{4 if a.config5 else 3}]-like{' (heating, BB + PL + QPL SEDs, device-built tables)' if a.config5 else ''}: {n}^3 log-normal density, {a.sources} sources, rank {a.rank} of {a.ranks} "
                        f"({mine} sources on this GPU), neutral start, dt = {a.dt_years:g} yr, batch {a.batch}",
            "niter": niter, "wall_s": wall, "swept_cell_updates_per_s": swept / wall,
            "nominal_cell_updates_per_s": n ** 3 * mine * niter / wall,
