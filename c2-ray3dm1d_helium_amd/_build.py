@@ -10,7 +10,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libc2ray_hip.so"
 SOURCES = [CSRC / "c2ray_hip.hip"]
-HEADERS = [CSRC / "c2ray_device.hpp", PKG.parent / "include" / "c2ray_hip.h"]
+HEADERS = [CSRC / "c2ray_device.hpp", CSRC / "c2ray_math.hpp", CSRC / "c2ray_math_tables.hpp",
+           PKG.parent / "include" / "c2ray_hip.h"]
 # -ffp-contract=off: the reference's flang -O2 x86-64 build performs no FMA contraction; fusing
 # a*b+c on the GPU changes results in the last bit, which the outer iteration amplifies.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
@@ -33,12 +34,25 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
-    # C2R_EXTRA_HIPCC_FLAGS: timing-only ablation builds (-DC2R_ABL_*), never for results
-    extra = os.environ.get("C2R_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-o", str(LIB), *map(str, SOURCES)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-    if verbose:
-        print(" ".join(cmd))
+    # One builder at a time (N ranks of a multi-GPU launch import the package together), and the library
+    # appears atomically: compile to a private name, then rename.
+    import fcntl
+    with open(PKG / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():   # another process built it while we waited
+                return LIB
+            # C2R_EXTRA_HIPCC_FLAGS: timing-only ablation builds (-DC2R_ABL_*), never for results
+            extra = os.environ.get("C2R_EXTRA_HIPCC_FLAGS", "").split()
+            tmp = LIB.with_name(f"{LIB.name}.tmp{os.getpid()}")
+            cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-o", str(tmp), *map(str, SOURCES)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                tmp.unlink(missing_ok=True)
+                raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB)
+            if verbose:
+                print(" ".join(cmd))
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
