@@ -179,6 +179,10 @@ def test_larger_boxes_vs_oracle(pkg, orc, otables, tables, n, nsrc, iso):
     for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)] + ([] if iso else [("phiheat", s.phiheat)]):
         q = stats(k, rel_err(rates[k], ref), log)
         assert np.array_equal(rates[k], ref), (k, q)
+    # the sub-box bookkeeping: same number of sub-boxes per source (the while-test on the photon loss, decided
+    # from a sampled loss where that is safe) and the same kept loss up to the order of its sum
+    assert rates["sum_nbox"] == int(s.c.sum_nbox)
+    assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-13
     dt = 1.0e6 * hp.YEAR
     e.upload_rates(s.phih, s.phihe, s.phiheat)
     conv = e.global_pass(dt)
@@ -742,3 +746,52 @@ def test_evolve3d_restart_argument(pkg, tables, gold):
     assert ev2.conv_flags == [int(x) for x in o["conv_flags"]][4:]
     assert np.array_equal(mat2.xh, o["xh"]) and np.array_equal(mat2.xhe, o["xhe"])
     assert np.array_equal(mat2.temperature_grid, o["temperature"])
+
+
+@pytest.mark.parametrize("iso", [True, False])
+def test_early_stopping_subboxes_vs_oracle(pkg, orc, otables, tables, iso):
+    """Sources in gas of very different opacity on a 64^3 mesh (up to four sub-box rounds): some stop after the
+    first or third round because the photon loss through the box surface falls below 1e-10 of their flux
+    (evolve_source.F90:136-144), others run to the full mesh.  Exercises the sampled loss test, its exact fallback (k_loss_exact) and the
+    tile-list rates launches against the oracle's serial sweep: columns, rates, sub-box counts bit for bit,
+    the kept loss up to the order of its sum."""
+    n, nsrc = 64, 5
+    rng = np.random.default_rng(11)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc)) * 3.0
+    # the stop test compares the loss with the source's own flux, so what decides is the opacity around a
+    # source: neutral fraction rising from 10^-2.6 at i = 1 to ~1 at i = n
+    xn = np.minimum(0.99, 10.0 ** (-2.6 + 2.4 * (np.arange(nc) % n) / n + rng.uniform(-0.2, 0.2, nc)))
+    xh = np.concatenate([xn, 1.0 - xn])
+    xhe = np.concatenate([xn, 0.8 * (1.0 - xn), 0.2 * (1.0 - xn)])
+    temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.2, nc))).astype(np.float32), 3)
+    srcpos = rng.integers(1, n + 1, size=(nsrc, 3)).astype(np.int32)
+    srcpos[:, 0] = [3, 16, 30, 45, 60]
+    flux = np.array([3e3, 1e5, 3e6, 1e2, 1e8])
+    mat = pkg.Material(ndens, xh, xhe, temp, iso, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, flux, 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    st = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens, hp.reccoef(1.0e4))
+    s = orc.State(st, xh, xhe, temp)
+    orc.begin_step(s)
+    orc.pass_all_sources(otables, st, s)
+    nbox_ref = int(s.c.sum_nbox)
+    assert nsrc < nbox_ref < 4 * nsrc                    # a mix of early and late stops
+    for batch in (2, 8):
+        e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, tables)
+        e.set_batch(batch)
+        e.begin_step()
+        e.set_rates_to_zero()
+        e.pass_sources(1, 1)
+        rates = e.download_rates()
+        cols = e.download_columns()
+        e.close()
+        assert rates["sum_nbox"] == nbox_ref
+        assert np.array_equal(cols["coldensh_out"], s.coldensh_out) and np.array_equal(cols["coldenshe_out"], s.coldenshe_out)
+        for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)] + ([] if iso else [("phiheat", s.phiheat)]):
+            assert np.array_equal(rates[k], ref), (batch, k)
+        assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-13
