@@ -371,7 +371,7 @@ k_col_to_grid(Grid g, SrcInfo S, const double *__restrict__ cs, double *__restri
 // (evolve_point.F90:246-306 with photoion_rates, radiation_photoionrates.f90:108-277).
 // rates layout: [phih | phihe0 | phihe1 | phiheat] each ncell.
 template <bool HEAT, bool MULTI>
-__global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? 4 : 5) : (HEAT ? 4 : 6))
+__global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? 4 : 4) : (HEAT ? 4 : 5))
 k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
         const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
         SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles, int tile_base) {
