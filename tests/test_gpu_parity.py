@@ -795,3 +795,55 @@ def test_early_stopping_subboxes_vs_oracle(pkg, orc, otables, tables, iso):
         for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)] + ([] if iso else [("phiheat", s.phiheat)]):
             assert np.array_equal(rates[k], ref), (batch, k)
         assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-13
+
+
+@pytest.mark.parametrize("iso", [True, False])
+def test_three_seds_on_a_random_box_vs_oracle(pkg, orc, tables, gold, iso):
+    """Black-body, power-law and quasar-like components in every on/off combination over five sources, on a
+    24^3 log-normal box: one pass + one global pass against the oracle, bit for bit -- the isothermal
+    multi-SED kernel included (the reference fixture of the -DPL -DQUASARS build is a heating run)."""
+    n = 24
+    rng = np.random.default_rng(21)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.6, nc))
+    x = 10.0 ** rng.uniform(-4, -0.3, nc)
+    xh, xhe = np.concatenate([1.0 - x, x]), np.concatenate([1.0 - x, 0.8 * x, 0.2 * x])
+    temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.2, nc))).astype(np.float32), 3)
+    srcpos = rng.integers(1, n + 1, size=(5, 3)).astype(np.int32)
+    bb = np.array([3e6, 0.0, 1e6, 0.0, 2e6])
+    pl = np.array([1e6, 2e6, 0.0, 0.0, 5e5])
+    qpl = np.array([0.0, 1e6, 3e6, 2e6, 5e5])
+    t = pkg.RadiationTables.load().add_sed_file(Path(__file__).parent / "golden" / "rad_tables_pl_qpl.npz")
+    with np.load(pkg.evolve.DEFAULT_TABLES) as z:
+        d = {k: z[k] for k in z.files}
+    zz = gold("rad_tables_pl_qpl.npz")
+    d.update({k: zz[k] for k in zz.files})
+    T = orc.Tables(d)
+    mat = pkg.Material(ndens, xh, xhe, temp, iso, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, bb, 1.0e48, NormFluxPL=pl, pl_S_star=2.0e48, NormFluxQPL=qpl, qpl_S_star=0.5e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, t)
+    e.set_batch(2)
+    e.begin_step()
+    e.set_rates_to_zero()
+    e.pass_sources(1, 1)
+    rates = e.download_rates()
+    st = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, bb, 1.0e48, ndens, hp.reccoef(1.0e4),
+                  normflux_pl=pl, normflux_qpl=qpl, pl_s_star=2.0e48, qpl_s_star=0.5e48)
+    s = orc.State(st, xh, xhe, temp)
+    orc.begin_step(s)
+    orc.pass_all_sources(T, st, s)
+    for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)] + ([] if iso else [("phiheat", s.phiheat)]):
+        assert np.array_equal(rates[k], ref), k
+    assert rates["sum_nbox"] == int(s.c.sum_nbox)
+    assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-13
+    dt = 1.0e6 * hp.YEAR
+    conv = e.global_pass(dt)
+    assert conv == orc.global_pass(T, st, s, dt)
+    it = e.download_iter_state()
+    assert np.array_equal(it["xh_av"], s.xh_av) and np.array_equal(it["xhe_av"], s.xhe_av)
+    e.close()
