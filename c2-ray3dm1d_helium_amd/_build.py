@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         try:
             if not force and not needs_build():   # another process built it while we waited
                 return LIB
-            # C2R_EXTRA_HIPCC_FLAGS: timing-only ablation builds (-DC2R_ABL_*), never for results
+            # C2R_EXTRA_HIPCC_FLAGS: extra compiler flags for experiments
             extra = os.environ.get("C2R_EXTRA_HIPCC_FLAGS", "").split()
             tmp = LIB.with_name(f"{LIB.name}.tmp{os.getpid()}")
             cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-o", str(tmp), *map(str, SOURCES)]

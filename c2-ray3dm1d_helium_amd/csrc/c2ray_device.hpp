@@ -139,9 +139,6 @@ C2R_HD Recip make_recip(double b) {
   return R;
 }
 C2R_HD double div_recip(double a, const Recip &R) {
-#ifdef C2R_ABL_DIVVOL // timing-only ablation (wrong results): what do the corrected divisions cost?
-  return a * R.y;
-#endif
   const double aa = fabs(a);
   if (R.ok && ((aa > 0x1p-500 && aa < 0x1p500) || a == 0.0)) {
     const double q = a * R.y;
@@ -397,11 +394,7 @@ struct TauPos {
   double residual;
 };
 C2R_HD TauPos tau_table_position(double tau) {
-#ifdef C2R_ABL_LOG // timing-only ablation (wrong results): what does log10 cost?
-  double lt = dmax(1.0e-20, tau) * 1.0e-3 - 3.0;
-#else
   double lt = C2R_MATH_LOG10N(dmax(1.0e-20, tau)); // positive, normal and finite by construction
-#endif
   // (lt - minlogtau)/dlogtau, correctly rounded through the constant's reciprocal (div_recip);
   // the numerator lies in [0, 24.5], dlogtau = 0x1.89374bc6a7efap-7
   const double num = lt - minlogtau;
@@ -418,9 +411,6 @@ C2R_HD TauPos tau_table_position(double tau) {
 // :310-326; col points at row 0 of a column with pitch NTAUP whose row 2001 duplicates row 2000,
 // so that ipos_p1 = min(NumTau, ipos+1) needs no clamp: (c[2001]-c[2000])*residual == 0 exactly.
 C2R_HD double read_table(const double *col, const TauPos &p) {
-#ifdef C2R_ABL_TABLE // timing-only ablation (wrong results): what do the table gathers cost?
-  return p.residual + (double)p.ipos;
-#endif
   double a = col[p.ipos], b = col[p.ipos + 1];
   return a + (b - a) * p.residual;
 }
@@ -494,19 +484,11 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
     // species split of this band (scale_int2 / scale_int3)
     double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
     if (b >= NB1 && b < NB1 + NB2) {
-#ifdef C2R_ABL_SCALE // timing-only ablation (wrong results)
-      double forscaleing = (sHI * cell_HI + sHeI * cell_HeI);
-#else
       double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI);
-#endif
       sc_HI = sHI * cell_HI * forscaleing;
       sc_HeI = sHeI * cell_HeI * forscaleing;
     } else if (b >= NB1 + NB2) {
-#ifdef C2R_ABL_SCALE
-      double forscaleing = (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
-#else
       double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
-#endif
       sc_HI = cell_HI * sHI * forscaleing;
       sc_HeI = cell_HeI * sHeI * forscaleing;
       sc_HeII = cell_HeII * sHeII * forscaleing;
