@@ -6,10 +6,10 @@
 #   cp gpurun_out/prof_bench/pmc_summary.json        profiles/rNN_bench_pmc_summary.json
 set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_bench
+OUT=$ROOT/gpurun_out/${PROF_NAME:-prof_bench}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline ${BENCH_EXTRA_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 i=0
