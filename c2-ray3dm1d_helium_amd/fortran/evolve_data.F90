@@ -6,37 +6,31 @@
 !! them); coldensh_out etc. are scratch of the reference's CPU sweep and have no host mirror.
 module evolve_data
 
-  use precision, only: dp
-  use my_mpi
-  use sizes, only: mesh, Ndim
-  use radiation_sizes, only: NumFreqBnd
-  use file_admin, only: logf
   use, intrinsic :: iso_c_binding, only: c_ptr, c_null_ptr, c_int
   use c2ray_hip, only: c2r_create, c2r_error_text
+  use file_admin, only: logf
+  use my_mpi                                  ! rank
+  use precision, only: dp
+  use radiation_sizes, only: NumFreqBnd
+  use sizes, only: Ndim, mesh
 
   implicit none
-
   save
 
-  !> Periodic boundary conditions, has to be true for this version
-  logical,parameter :: periodic_bc = .true.
+  !> the sweep wraps around the mesh edges (the only mode the reference supports here)
+  logical, parameter :: periodic_bc = .true.
 
-  !> H Photo-ionization rate on the entire grid
-  real(kind=dp),dimension(:,:,:),allocatable :: phih_grid
-  !> He Photo-ionization rate on the entire grid
-  real(kind=dp),dimension(:,:,:,:),allocatable :: phihe_grid
-  !> Heating  rate on the entire grid
-  real(kind=dp),dimension(:,:,:),allocatable :: phiheat
-  !> Time-averaged H ionization fraction
-  real(kind=dp),dimension(:,:,:,:),allocatable :: xh_av
-  !> Time-averaged He ionization fraction
-  real(kind=dp),dimension(:,:,:,:),allocatable :: xhe_av
-  !> Intermediate result for H ionization fraction
-  real(kind=dp),dimension(:,:,:,:),allocatable :: xh_intermed
-  !> Intermediate result for He ionization fraction
-  real(kind=dp),dimension(:,:,:,:),allocatable :: xhe_intermed
-  !> Photon loss from the grid
-  real(kind=dp) :: photon_loss_all(1:NumFreqBnd)
+  ! host mirrors of device arrays, public under the reference's names
+  !> photo-ionisation rates summed over all sources: H, and He (components 0:1)
+  real(kind=dp), allocatable :: phih_grid(:,:,:), phihe_grid(:,:,:,:)
+  !> heating rate summed over all sources
+  real(kind=dp), allocatable :: phiheat(:,:,:)
+  !> ionisation fractions averaged over the time step: H (0:1), He (0:2)
+  real(kind=dp), allocatable :: xh_av(:,:,:,:), xhe_av(:,:,:,:)
+  !> ionisation fractions at the end of the time step, current iterate: H (0:1), He (0:2)
+  real(kind=dp), allocatable :: xh_intermed(:,:,:,:), xhe_intermed(:,:,:,:)
+  !> photons that left the mesh, per frequency band, summed over sources (and ranks)
+  real(kind=dp) :: photon_loss_all(NumFreqBnd)
 
   !> The device context (include/c2ray_hip.h); one per rank = one per GPU
   type(c_ptr) :: hip_ctx = c_null_ptr
@@ -45,25 +39,27 @@ module evolve_data
 
 contains
 
-  !> Allocate the arrays needed for evolve: host mirrors here, work arrays on the device
+  !> evolve_ini of the reference (files_for_3D/evolve_data.F90:74): host mirrors here, work arrays on
+  !! the device
   subroutine evolve_ini ()
 
     integer(c_int) :: ierr
     integer(c_int) :: cmesh(3)
     character(len=16) :: value
     integer :: length, status
+    integer :: n1, n2, n3
 
-    allocate(phih_grid(mesh(1),mesh(2),mesh(3)))
-    phih_grid=0.0 ! Needs value for initial output
-    allocate(phihe_grid(mesh(1),mesh(2),mesh(3),0:1))
-    phihe_grid=0.0
-    allocate(phiheat(mesh(1),mesh(2),mesh(3)))
-    phiheat=0.0 ! Needs value for initial output
-    allocate(xh_av(mesh(1),mesh(2),mesh(3),0:1))
-    allocate(xhe_av(mesh(1),mesh(2),mesh(3),0:2))
-    allocate(xh_intermed(mesh(1),mesh(2),mesh(3),0:1))
-    allocate(xhe_intermed(mesh(1),mesh(2),mesh(3),0:2))
-    photon_loss_all(:)=0.0
+    n1 = mesh(1)
+    n2 = mesh(2)
+    n3 = mesh(3)
+    ! the rate grids are written out before the first evolve3D call (output.F90), so they start at zero
+    allocate(phih_grid(n1,n2,n3), phiheat(n1,n2,n3), phihe_grid(n1,n2,n3,0:1))
+    phih_grid(:,:,:) = 0.0_dp
+    phiheat(:,:,:) = 0.0_dp
+    phihe_grid(:,:,:,:) = 0.0_dp
+    allocate(xh_av(n1,n2,n3,0:1), xh_intermed(n1,n2,n3,0:1))
+    allocate(xhe_av(n1,n2,n3,0:2), xhe_intermed(n1,n2,n3,0:2))
+    photon_loss_all(:) = 0.0_dp
 
     ! one rank per GPU: rank r of a node uses device r unless C2RAY_HIP_DEVICE says otherwise
     hip_device = rank
