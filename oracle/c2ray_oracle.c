@@ -15,6 +15,9 @@
 #include "c2ray_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -926,6 +929,20 @@ int orc_global_pass(const orc_tables *tb, const orc_step *st, orc_state *s, doub
   return conv_flag;
 }
 
+/* the same over `nthreads` OpenMP threads: cells are independent, the count is an integer sum */
+int orc_global_pass_threads(const orc_tables *tb, const orc_step *st, orc_state *s, double dt, int nthreads) {
+  const long long ncell = (long long)st->mesh[0] * st->mesh[1] * st->mesh[2];
+  int conv_flag = 0;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(nthreads) reduction(+ : conv_flag)
+  for (long long q = 0; q < ncell; q++) {
+    int c = 0;
+    evolve0D_global(tb, st, s, dt, (size_t)q, &c);
+    conv_flag += c;
+  }
+  return conv_flag;
+}
+
 /* files_for_3D/evolve.F90:78-229, restart == 0 */
 int orc_evolve3d(const orc_tables *tb, const orc_step *st, orc_state *s, double dt, int max_iter) {
   const size_t ncell = (size_t)st->mesh[0] * st->mesh[1] * st->mesh[2];
@@ -962,6 +979,105 @@ int orc_evolve3d(const orc_tables *tb, const orc_step *st, orc_state *s, double 
   }
   s->niter = niter;
   return niter;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * do_source in L-infinity shell order, the cells of a shell in parallel (OpenMP).
+ *
+ * Not how the reference orders its sweep (evolve2D / the 8-way OpenMP decomposition of
+ * evolve_source.F90:158-189), but the order the HIP kernels use: every upstream corner cinterp reads lies
+ * in a smaller shell around the source, or in the same shell with an interpolation weight that is
+ * exactly 0.  Columns and rates therefore come out bit for bit as in the serial sweep (each cell is
+ * written once, from inputs that are complete); only the photon loss, a sum over boundary cells, is
+ * added up in a different order.  Used (a) as a CPU proof of that statement (tests/) and (b) as the
+ * all-cores CPU baseline of bench.py.  (A same-shell corner may be read while another thread writes it;
+ * its weight is 0 and the value finite either way.)
+ */
+typedef struct { int p[3]; } cellpos;
+
+int orc_do_source_shells(const orc_tables *tb, const orc_step *st, orc_state *s, int ns, double *loss_out, int nthreads) {
+  const size_t ncell = (size_t)st->mesh[0] * st->mesh[1] * st->mesh[2];
+  const int *src = st->srcpos + 3 * (ns - 1);
+  int lastpos_r[3], lastpos_l[3];
+  memset(s->coldensh_out, 0, ncell * sizeof(double));
+  memset(s->coldenshe_out, 0, 2 * ncell * sizeof(double));
+  int smax_all = 0;
+  for (int d = 0; d < 3; d++) {
+    lastpos_r[d] = src[d] + imin(MAX_SUBBOX, st->mesh[d] / 2 - 1 + st->mesh[d] % 2);
+    lastpos_l[d] = src[d] - imin(MAX_SUBBOX, st->mesh[d] / 2);
+    smax_all = imax(smax_all, st->mesh[d] / 2);
+  }
+  cellpos *cells = malloc(sizeof(cellpos) * (size_t)(24 * (size_t)smax_all * smax_all + 2));
+  if (nthreads < 1) nthreads = 1;
+  double *tloss = malloc(sizeof(double) * (size_t)nthreads);
+  int nbox = 0, s_done = -1;
+  double total_source_flux = st->normflux[ns - 1] * st->s_star;
+  if (st->normflux_pl) total_source_flux = total_source_flux + st->normflux_pl[ns - 1] * st->pl_s_star;
+  if (st->normflux_qpl) total_source_flux = total_source_flux + st->normflux_qpl[ns - 1] * st->qpl_s_star;
+  double photon_loss_src = total_source_flux;
+  int last_r[3], last_l[3];
+  for (int d = 0; d < 3; d++) { last_r[d] = src[d]; last_l[d] = src[d]; }
+  while (photon_loss_src > F(1e-10) * total_source_flux && last_r[2] < lastpos_r[2] && last_l[2] > lastpos_l[2]) {
+    nbox++;
+    photon_loss_src = 0.0;
+    int smax = 0;
+    for (int d = 0; d < 3; d++) {
+      last_r[d] = imin(src[d] + SUBBOXSIZE * nbox, lastpos_r[d]);
+      last_l[d] = imax(src[d] - SUBBOXSIZE * nbox, lastpos_l[d]);
+      smax = imax(smax, imax(last_r[d] - src[d], src[d] - last_l[d]));
+    }
+    for (int sh = s_done + 1; sh <= smax; sh++) {
+      /* the cells of shell sh inside the box */
+      int n = 0;
+      for (int dk = imax(-sh, last_l[2] - src[2]); dk <= imin(sh, last_r[2] - src[2]); dk++)
+        for (int dj = imax(-sh, last_l[1] - src[1]); dj <= imin(sh, last_r[1] - src[1]); dj++) {
+          const int face = (dk == sh || dk == -sh || dj == sh || dj == -sh);
+          const int ilo = imax(-sh, last_l[0] - src[0]), ihi = imin(sh, last_r[0] - src[0]);
+          if (face) {
+            for (int di = ilo; di <= ihi; di++) { cells[n].p[0] = src[0] + di; cells[n].p[1] = src[1] + dj; cells[n].p[2] = src[2] + dk; n++; }
+          } else {
+            if (-sh >= ilo) { cells[n].p[0] = src[0] - sh; cells[n].p[1] = src[1] + dj; cells[n].p[2] = src[2] + dk; n++; }
+            if (sh <= ihi && sh != 0) { cells[n].p[0] = src[0] + sh; cells[n].p[1] = src[1] + dj; cells[n].p[2] = src[2] + dk; n++; }
+          }
+        }
+      for (int t = 0; t < nthreads; t++) tloss[t] = 0.0;
+#pragma omp parallel num_threads(nthreads)
+      {
+        sweep_ctx cx;
+        for (int d = 0; d < 3; d++) { cx.last_r[d] = last_r[d]; cx.last_l[d] = last_l[d]; }
+        cx.photon_loss_src_thread = 0.0;
+#pragma omp for schedule(static)
+        for (int c = 0; c < n; c++) evolve0D(tb, st, s, cells[c].p, ns, &cx);
+        int me = 0;
+#ifdef _OPENMP
+        me = omp_get_thread_num();
+#endif
+        tloss[me] = cx.photon_loss_src_thread;
+      }
+      for (int t = 0; t < nthreads; t++) photon_loss_src = photon_loss_src + tloss[t];
+    }
+    s_done = smax;
+  }
+  free(cells);
+  free(tloss);
+  if (loss_out) *loss_out = photon_loss_src;
+  return nbox;
+}
+
+/* set_rates_to_zero + all sources through orc_do_source_shells */
+void orc_pass_all_sources_shells(const orc_tables *tb, const orc_step *st, orc_state *s, int nthreads) {
+  const size_t ncell = (size_t)st->mesh[0] * st->mesh[1] * st->mesh[2];
+  memset(s->phih, 0, ncell * sizeof(double));
+  memset(s->phihe, 0, 2 * ncell * sizeof(double));
+  memset(s->phiheat, 0, ncell * sizeof(double));
+  memset(s->photon_loss, 0, sizeof(s->photon_loss));
+  s->sum_nbox = 0;
+  for (int ns = 1; ns <= st->nsrc; ns++) {
+    double loss = 0.0;
+    int nbox = orc_do_source_shells(tb, st, s, ns, &loss, nthreads);
+    s->photon_loss[0] = s->photon_loss[0] + loss;
+    s->sum_nbox += nbox;
+  }
 }
 
 /* ---------------------------------------------------------------------------------------------

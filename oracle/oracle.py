@@ -242,8 +242,23 @@ def pass_all_sources(tables, step, state):
     lib().orc_pass_all_sources(C.byref(tables.c), C.byref(step.c), C.byref(state.c))
 
 
+def pass_all_sources_shells(tables, step, state, nthreads=1):
+    """pass_all_sources in L-infinity shell order, the cells of a shell over `nthreads` OpenMP threads."""
+    l = lib()
+    l.orc_pass_all_sources_shells.restype = None
+    l.orc_pass_all_sources_shells.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    l.orc_pass_all_sources_shells(C.byref(tables.c), C.byref(step.c), C.byref(state.c), int(nthreads))
+
+
 def global_pass(tables, step, state, dt):
     return lib().orc_global_pass(C.byref(tables.c), C.byref(step.c), C.byref(state.c), C.c_double(dt))
+
+
+def global_pass_threads(tables, step, state, dt, nthreads=1):
+    l = lib()
+    l.orc_global_pass_threads.restype = C.c_int
+    l.orc_global_pass_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int]
+    return int(l.orc_global_pass_threads(C.byref(tables.c), C.byref(step.c), C.byref(state.c), float(dt), int(nthreads)))
 
 
 def do_source(tables, step, state, ns):

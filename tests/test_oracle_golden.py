@@ -145,3 +145,41 @@ def test_table_construction_equals_reference(orc, pkg, gold):
                 got = T[f"{kind}_{tt}"].reshape(ncol, 2001)[used]
                 want = sed[f"{pre}{kind}_{tt}"].reshape(ncol, 2001)[used]
                 assert np.array_equal(got, want), (pre, kind, tt)
+
+
+@pytest.mark.parametrize("n,nsrc,iso", [(22, 3, True), (40, 4, False)])
+def test_shell_order_parallel_sweep_equals_serial_sweep(orc, otables, pkg, n, nsrc, iso):
+    """The ordering the HIP kernels rely on, proved on the CPU: sweeping a source in L-infinity shells with the
+    cells of a shell in parallel (8 OpenMP threads) leaves the columns and the rate grids of the reference's
+    serial sweep order bit for bit; only the photon loss (a sum over boundary cells) is added up in another
+    order.  The global pass is cell-parallel trivially."""
+    rng = np.random.default_rng(5)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0, 0.5, nc))
+    x = 10.0 ** rng.uniform(-4, -0.3, nc)
+    xh, xhe = np.concatenate([1 - x, x]), np.concatenate([1 - x, 0.8 * x, 0.2 * x])
+    temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.2, nc))).astype(np.float32), 3)
+    srcpos = rng.integers(1, n + 1, size=(nsrc, 3)).astype(np.int32)
+    srcpos[0] = (1, n, n // 2)
+    flux = 10.0 ** rng.uniform(5, 7, nsrc)
+    st = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, iso, 1e4, 1.0, srcpos, flux, 1e48, ndens, hp.reccoef(1e4))
+    a = orc.State(st, xh, xhe, temp)
+    orc.begin_step(a)
+    orc.pass_all_sources(otables, st, a)
+    for threads in (1, 8):
+        b = orc.State(st, xh, xhe, temp)
+        orc.begin_step(b)
+        orc.pass_all_sources_shells(otables, st, b, threads)
+        assert np.array_equal(a.coldensh_out, b.coldensh_out) and np.array_equal(a.coldenshe_out, b.coldenshe_out)
+        assert np.array_equal(a.phih, b.phih) and np.array_equal(a.phihe, b.phihe) and np.array_equal(a.phiheat, b.phiheat)
+        assert a.c.sum_nbox == b.c.sum_nbox
+        assert abs(a.photon_loss[0] - b.photon_loss[0]) <= 1e-13 * a.photon_loss[0]
+    dt = 1.0e6 * hp.YEAR
+    ca = orc.global_pass(otables, st, a, dt)
+    cb = orc.global_pass_threads(otables, st, b, dt, 8)
+    assert ca == cb and np.array_equal(a.xh_av, b.xh_av) and np.array_equal(a.xhe_intermed, b.xhe_intermed)
+    if not iso:
+        assert np.array_equal(a.temperature, b.temperature)
