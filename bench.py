@@ -84,7 +84,7 @@ def cpu_baseline(pkg, mesh=160, nsrc=8):
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as orc
     orc.build()
-    threads = max(1, min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     mat, grid, src, cosmo = config3_inputs(pkg, mesh, nsrc)
     with np.load(pkg.evolve.DEFAULT_TABLES) as t:
         T = orc.Tables({k: t[k] for k in t.files})
