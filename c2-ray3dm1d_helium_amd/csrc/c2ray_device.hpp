@@ -350,8 +350,11 @@ struct CoolData {
 };
 
 // thermal.f90:22-174 (cosmological = .true.)
-C2R_HD void thermal(const CoolData &cd, double dt, double &end_temper, double &avg_temper, double ndens_electron,
-                    double ndens_atom, const IonStates &ion, double heating) {
+// `work` / `budget` (optional): the caller's running count of sub-steps and its ceiling.  When the count
+// passes a non-zero ceiling the routine returns true at once and its outputs are meaningless: the caller
+// abandons the cell and redoes it from scratch later (k_chemistry's tiers).
+C2R_HD bool thermal(const CoolData &cd, double dt, double &end_temper, double &avg_temper, double ndens_electron,
+                    double ndens_atom, const IonStates &ion, double heating, int *work = nullptr, int budget = 0) {
   double internal_energy =
       temper2pressr(end_temper, ndens_atom, electrondens(ndens_atom, ion.h_old, ion.he_old)) / gamma1;
   double cosmo_cool_rate = cosmo_cool(internal_energy, cd.zred, cd.H0, cd.Omega0);
@@ -363,6 +366,9 @@ C2R_HD void thermal(const CoolData &cd, double dt, double &end_temper, double &a
     const double eldens_av = electrondens(ndens_atom, ion.h_av, ion.he_av);
     for (;;) {
       i_heating++;
+      if (work) {
+        if (++(*work) > budget && budget) return true;
+      }
       double cooling =
           coolin(cd.cool, cd.mintemp, cd.dtemp, ndens_atom, ndens_electron, ion.h_av, ion.he_av, end_temper) +
           cosmo_cool_rate;
@@ -385,6 +391,7 @@ C2R_HD void thermal(const CoolData &cd, double dt, double &end_temper, double &a
     if (dt > 0.0) avg_temper = avg_temper / dt; else avg_temper = initial_temp;
     end_temper = pressr2temper(internal_energy * gamma1, ndens_atom, electrondens(ndens_atom, ion.h, ion.he));
   }
+  return false;
 }
 
 // ----------------------------------------------------------------------------------------

@@ -465,11 +465,20 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
-            const float *__restrict__ clumping_grid, size_t q_first, size_t q_end) {
+            const float *__restrict__ clumping_grid, size_t q_first, size_t q_end, const int *__restrict__ list,
+            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist) {
+  // Cells are taken from the range [q_first, q_end) or, when `list` is given, from list[q_first .. q_end).
+  // Heating runs (hist != null): budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps --
+  // nothing of it is stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds
+  // only such cells (c2r_global_pass_finish).  hist counts the cells per power of two of sub-steps.
   const size_t nc = g.ncell;
-  const size_t q = q_first + (size_t)blockIdx.x * C2R_CHEM_BLOCK + threadIdx.x;
+  const size_t idx = q_first + (size_t)blockIdx.x * C2R_CHEM_BLOCK + threadIdx.x;
   int notconv = 0;
-  if (q < q_end) {
+  int bucket = -1;
+  if (idx < q_end) {
+    const size_t q = list ? (size_t)list[idx] : idx;
+    int work = 0;
+    bool dropped = false;
     // clumping_point for type_of_clumping = 5 (evolve_point.F90:483-484; REAL(4) grid)
     const double clumping = clumping_grid ? (double)clumping_grid[q] : sc.clumping;
     IonStates ion;
@@ -530,7 +539,12 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
       ion.he_av[1] = (ion.he_av[1] + oldhe1av) / 2.0;
       de = electrondens(ndens_p, ion.h_av, ion.he_av);
       temper1 = temper0;
-      if (HEAT) thermal(sc.cd, dt, temper1, avg_temper, de, ndens_p, ion, heat);
+      if (HEAT) {
+        if (thermal(sc.cd, dt, temper1, avg_temper, de, ndens_p, ion, heat, &work, budget)) {
+          dropped = true;
+          break;
+        }
+      }
 
       const double mfc = minimum_fractional_change, mfa = minimum_fraction_of_atoms;
       if ((fabs((ion.h_av[0] - h0_old) / ion.h_av[0]) < mfc || ion.h_av[0] < mfa) &&
@@ -540,6 +554,10 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
         break;
       if (nit > 400) break;
     }
+    if (dropped) {
+      deferred[atomicAdd(ndeferred, 1)] = (int)q;
+    } else {
+    if (HEAT && hist) bucket = work > 0 ? 32 - __clz(work) : 0;
     // The reference keeps the coefficients in module-global variables (cgsconstants.f90:106-133): after
     // the global pass they hold what the LAST cell (mesh,mesh,mesh) computed last, and
     // photonstatistics:total_rates then uses those for every cell.  Export them for the host.
@@ -568,6 +586,18 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
     xh_av[q] = ion.h_av[0];     xh_av[q + nc] = ion.h_av[1];
     xhe_int[q] = ion.he[0];     xhe_int[q + nc] = ion.he[1];     xhe_int[q + 2 * nc] = ion.he[2];
     xhe_av[q] = ion.he_av[0];   xhe_av[q + nc] = ion.he_av[1];   xhe_av[q + 2 * nc] = ion.he_av[2];
+    } // not dropped
+  }
+  if (HEAT && hist) { // one atomic per wave and distinct bucket
+    unsigned long long live = __ballot(bucket >= 0);
+    const int lane = threadIdx.x & 63;
+    while (live) {
+      const int leader = __ffsll((long long)live) - 1;
+      const int b = __shfl(bucket, leader, 64);
+      const unsigned long long same = __ballot(bucket == b);
+      if (lane == leader) atomicAdd(&hist[b], (int)__popcll(same));
+      live &= ~same;
+    }
   }
   // conv_flag = conv_flag + 1 (evolve_point.F90:423): integer count, order-independent
   const unsigned long long m = __ballot(notconv);
@@ -781,6 +811,10 @@ struct c2r_ctx {
   size_t ev_used = 0;
 
   int chem_pieces = 0;              // pieces of the open global pass (c2r_global_pass_cells)
+  double chem_dt = 0.0;
+  int chem_b1 = 0;                  // sub-step ceiling of the next heating global pass's first launch (0: none)
+  int *d_defer[2] = {nullptr, nullptr}; // cells dropped by a tier of the heating global pass (ping-pong lists)
+  int *d_chemctl = nullptr;         // {count of list 0, count of list 1, histogram[CHEM_HIST]}
   // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
   bool pass_open = false;
   int pass_slabs = 0;
@@ -940,7 +974,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_stateT, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base};
+                  c->d_rates_own, c->d_stateT, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
@@ -1761,48 +1795,106 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
 // The global pass over a range of cells, queued behind `after_event` (an event of another stream, e.g. the
 // one on which the caller's sum over ranks of these cells completes; may be null).  A range starting at
 // cell 0 opens a pass (zeroes the non-converged count); c2r_global_pass_finish closes it.
+// Heating global pass in tiers.  The number of sub-steps thermal() takes spans four orders of magnitude (cells at
+// an ionisation front sub-cycle the energy equation hundreds to thousands of times next to neighbours that
+// need two), and a wave lasts as long as its slowest lane: measured on a 1024-source heating run, 90 % of the
+// lane-time of a plain launch was idle.  So the first launch of a pass gives every cell `chem_b1` sub-steps;
+// the cells that need more are dropped and redone, densely packed, by follow-up launches with ceilings 8 and
+// 64 times higher and finally without one.  chem_b1 follows the histogram of the previous pass: twice its
+// 90th percentile, or 0 (one plain launch) while nothing is known yet or when there is no tail to cut.
+// Results do not depend on any of this: a dropped cell stores nothing and is recomputed from the same inputs.
+// (Cells that run into the 400-iteration cap of do_chemistry with few sub-steps stay in the first launch:
+// each is one long serial chain, and the earlier it starts the better.)
+constexpr int CHEM_HIST = 24;
+
+static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first, size_t count, const int *list, int budget,
+                            int *deferred, int *ndeferred) {
+  if (count == 0) return 0;
+  const Grid g = c->g;
+  const StepScalars sc = scalars(c);
+  const int nblk = (int)((count + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
+  if (c->isothermal)
+    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, 0,
+                       (int *)nullptr, (int *)nullptr, (int *)nullptr);
+  else
+    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
+                       ndeferred, c->d_chemctl + 2);
+  HIPCHK(c, hipGetLastError());
+  c->tm.chem_launches++;
+  return 0;
+}
+
 extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, size_t ncells, void *after_event) {
   if (!c) return 1;
   if (check_ready(c, "c2r_global_pass_cells")) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   const Grid g = c->g;
   if (first_cell > g.ncell || ncells > g.ncell - first_cell) return fail(c, "c2r_global_pass_cells: range outside the mesh");
-  const StepScalars sc = scalars(c);
+  const bool heat = !c->isothermal;
+  if (heat && !c->d_defer[0]) {
+    for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * g.ncell));
+    HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (2 + CHEM_HIST))); // two list counts, then the histogram
+  }
   if (first_cell == 0) {
     HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
+    if (heat) HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (2 + CHEM_HIST), c->stream));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    // the second stream takes every other piece: it must see the zeroed counter (and everything before)
+    // the second stream takes every other piece: it must see the zeroed counters (and everything before)
     HIPCHK(c, hipEventRecord(c->ev_sweep_done[0], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
     c->tm.chem_launches = 0;
     c->chem_pieces = 0;
+    c->chem_dt = dt;
   }
-  // Pieces alternate between the two streams: the cells of a piece need very different numbers of
-  // do_chemistry iterations, so every launch ends in a long thin tail; on alternating streams the next
-  // piece fills the chip while the previous one drains.
+  // Pieces alternate between the two streams: every launch ends in a long thin tail; on alternating streams
+  // the next piece fills the chip while the previous one drains.
   hipStream_t st = (c->chem_pieces++ & 1) ? c->stream2 : c->stream;
   if (after_event) HIPCHK(c, hipStreamWaitEvent(st, static_cast<hipEvent_t>(after_event), 0));
-  if (ncells == 0) return 0;
-  const int nblk = (int)((ncells + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
-  if (c->isothermal)
-    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
-                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first_cell, first_cell + ncells);
-  else
-    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
-                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first_cell, first_cell + ncells);
-  HIPCHK(c, hipGetLastError());
-  c->tm.chem_launches++;
-  return 0;
+  return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, heat ? c->chem_b1 : 0, c->d_defer[0], c->d_chemctl);
 }
 
 extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  // join the second stream, then read the count on the first
+  // join the second stream
   HIPCHK(c, hipEventRecord(c->ev_rates_done[0], c->stream2));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[0], 0));
+  if (!c->isothermal) {
+    if (c->chem_b1 > 0) { // later tiers: the cells dropped by the previous one, densely packed
+      int cur = 0;
+      long long ceiling = c->chem_b1;
+      for (int t = 1; t <= 3; t++) {
+        int n = 0;
+        HIPCHK(c, hipMemcpyAsync(&n, c->d_chemctl + cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n == 0) break;
+        const int nxt = cur ^ 1;
+        ceiling *= 8;
+        HIPCHK(c, hipMemsetAsync(c->d_chemctl + nxt, 0, sizeof(int), c->stream));
+        if (launch_chemistry(c, c->stream, c->chem_dt, 0, (size_t)n, c->d_defer[cur], t == 3 ? 0 : (int)ceiling,
+                             c->d_defer[nxt], c->d_chemctl + nxt))
+          return 1;
+        cur = nxt;
+      }
+    }
+    // the next pass's first ceiling from this pass's histogram (bucket b: sub-step counts in [2^(b-1), 2^b))
+    int hist[CHEM_HIST];
+    HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    long long total = 0, acc = 0;
+    for (int b = 0; b < CHEM_HIST; b++) total += hist[b];
+    int b90 = 0, b999 = 0;
+    for (int b = 0; b < CHEM_HIST; b++) {
+      acc += hist[b];
+      if (acc * 10 < total * 9) b90 = b + 1;
+      if (acc * 1000 < total * 999) b999 = b + 1;
+    }
+    c->chem_b1 = (total > 0 && b999 >= b90 + 3) ? std::max(16, 1 << std::min(b90 + 1, 20)) : 0;
+  }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
