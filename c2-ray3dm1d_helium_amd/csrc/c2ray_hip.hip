@@ -466,16 +466,19 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
             const float *__restrict__ clumping_grid, size_t q_first, size_t q_end, const int *__restrict__ list,
-            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist) {
+            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist, int part) {
   // Cells are taken from the range [q_first, q_end) or, when `list` is given, from list[q_first .. q_end).
   // Heating runs (hist != null): budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps --
   // nothing of it is stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds
   // only such cells (c2r_global_pass_finish).  hist counts the cells per power of two of sub-steps.
+  // part 0: every block; part 1: only every 64th block (the sample a heating pass starts with, launched with a
+  // 64 times smaller grid); part 2: all the others.
   const size_t nc = g.ncell;
-  const size_t idx = q_first + (size_t)blockIdx.x * C2R_CHEM_BLOCK + threadIdx.x;
+  const size_t blk = part == 1 ? (size_t)blockIdx.x * 64 : (size_t)blockIdx.x;
+  const size_t idx = q_first + blk * C2R_CHEM_BLOCK + threadIdx.x;
   int notconv = 0;
   int bucket = -1;
-  if (idx < q_end) {
+  if (idx < q_end && !(part == 2 && (blk & 63) == 0)) {
     const size_t q = list ? (size_t)list[idx] : idx;
     int work = 0;
     bool dropped = false;
@@ -812,7 +815,10 @@ struct c2r_ctx {
 
   int chem_pieces = 0;              // pieces of the open global pass (c2r_global_pass_cells)
   double chem_dt = 0.0;
-  int chem_b1 = 0;                  // sub-step ceiling of the next heating global pass's first launch (0: none)
+  int chem_b1 = 0;                  // sub-step ceiling of the open heating global pass's first launch (0: none)
+  int chem_b1_next = 0;             // what the last pass's histogram suggests for the next one
+  int chem_sample = 0;              // ceiling the opening sample ran under (0: no sample in this pass)
+  int chem_list0_done = 0;          // entries of deferred list 0 the opening sample has already restarted
   int *d_defer[2] = {nullptr, nullptr}; // cells dropped by a tier of the heating global pass (ping-pong lists)
   int *d_chemctl = nullptr;         // {count of list 0, count of list 1, histogram[CHEM_HIST]}
   // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
@@ -1800,29 +1806,45 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
 // need two), and a wave lasts as long as its slowest lane: measured on a 1024-source heating run, 90 % of the
 // lane-time of a plain launch was idle.  So the first launch of a pass gives every cell `chem_b1` sub-steps;
 // the cells that need more are dropped and redone, densely packed, by follow-up launches with ceilings 8 and
-// 64 times higher and finally without one.  chem_b1 follows the histogram of the previous pass: twice its
-// 90th percentile, or 0 (one plain launch) while nothing is known yet or when there is no tail to cut.
+// 64 times higher and finally without one.  The ceiling is twice the 90th percentile of the histogram of
+// sub-steps per cell -- of the previous pass, or, when that one had no tail, of a sample this pass opens with --
+// or 0 (no ceiling) when there is no tail to cut.
 // Results do not depend on any of this: a dropped cell stores nothing and is recomputed from the same inputs.
 // (Cells that run into the 400-iteration cap of do_chemistry with few sub-steps stay in the first launch:
 // each is one long serial chain, and the earlier it starts the better.)
 constexpr int CHEM_HIST = 24;
 
+// first ceiling from a histogram of sub-steps per cell (bucket b: counts in [2^(b-1), 2^b)): twice the 90th
+// percentile if the 99.9th lies at least 8 times above it, otherwise none
+static int chemistry_ceiling(const int *hist) {
+  long long total = 0, acc = 0;
+  for (int b = 0; b < CHEM_HIST; b++) total += hist[b];
+  int b90 = 0, b999 = 0;
+  for (int b = 0; b < CHEM_HIST; b++) {
+    acc += hist[b];
+    if (acc * 10 < total * 9) b90 = b + 1;
+    if (acc * 1000 < total * 999) b999 = b + 1;
+  }
+  return (total > 0 && b999 >= b90 + 3) ? std::max(16, 1 << std::min(b90 + 1, 20)) : 0;
+}
+
 static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first, size_t count, const int *list, int budget,
-                            int *deferred, int *ndeferred) {
+                            int *deferred, int *ndeferred, int part = 0) {
   if (count == 0) return 0;
   const Grid g = c->g;
   const StepScalars sc = scalars(c);
-  const int nblk = (int)((count + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
+  int nblk = (int)((count + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
+  if (part == 1) nblk = (nblk + 63) / 64;
   if (c->isothermal)
     hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, 0,
-                       (int *)nullptr, (int *)nullptr, (int *)nullptr);
+                       (int *)nullptr, (int *)nullptr, (int *)nullptr, 0);
   else
     hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_chemctl + 2);
+                       ndeferred, c->d_chemctl + 2, part);
   HIPCHK(c, hipGetLastError());
   c->tm.chem_launches++;
   return 0;
@@ -1854,6 +1876,35 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
   // the next piece fills the chip while the previous one drains.
   hipStream_t st = (c->chem_pieces++ & 1) ? c->stream2 : c->stream;
   if (after_event) HIPCHK(c, hipStreamWaitEvent(st, static_cast<hipEvent_t>(after_event), 0));
+  if (heat && first_cell == 0) {
+    // ceiling of this pass: what the previous pass's histogram suggests; if that is "none" (nothing known yet,
+    // or the previous pass had no tail -- the first iteration of a time step typically has none and the second
+    // a heavy one), a sample decides: every 64th wave of this piece, itself under a ceiling so that it returns
+    // within a millisecond
+    c->chem_b1 = c->chem_b1_next;
+    if (c->chem_b1 == 0 && ncells >= (size_t)64 * 64 * C2R_CHEM_BLOCK) {
+      int hist[CHEM_HIST];
+      c->chem_sample = 512;
+      if (launch_chemistry(c, st, dt, first_cell, ncells, nullptr, c->chem_sample, c->d_defer[0], c->d_chemctl, 1)) return 1;
+      HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl, sizeof(int) * (2 + CHEM_HIST), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipStreamSynchronize(st));
+      const int dropped = hist[0];
+      // cells the sample dropped count as "above 512"
+      int h2[CHEM_HIST];
+      for (int b = 0; b < CHEM_HIST; b++) h2[b] = hist[2 + b];
+      h2[11] += dropped;
+      c->chem_b1 = chemistry_ceiling(h2);
+      // the few cells the sample dropped are long chains: they restart at once, without ceiling, beside the bulk
+      c->chem_list0_done = dropped;
+      if (dropped > 0) {
+        hipStream_t other = st == c->stream ? c->stream2 : c->stream;
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(other, c->ev_fork, 0));
+        if (launch_chemistry(c, other, dt, 0, (size_t)dropped, c->d_defer[0], 0, c->d_defer[1], c->d_chemctl + 1)) return 1;
+      }
+      return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, c->chem_b1, c->d_defer[0], c->d_chemctl, 2);
+    }
+  }
   return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, heat ? c->chem_b1 : 0, c->d_defer[0], c->d_chemctl);
 }
 
@@ -1864,36 +1915,31 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
   HIPCHK(c, hipEventRecord(c->ev_rates_done[0], c->stream2));
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[0], 0));
   if (!c->isothermal) {
-    if (c->chem_b1 > 0) { // later tiers: the cells dropped by the previous one, densely packed
-      int cur = 0;
-      long long ceiling = c->chem_b1;
-      for (int t = 1; t <= 3; t++) {
-        int n = 0;
-        HIPCHK(c, hipMemcpyAsync(&n, c->d_chemctl + cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (n == 0) break;
-        const int nxt = cur ^ 1;
-        ceiling *= 8;
-        HIPCHK(c, hipMemsetAsync(c->d_chemctl + nxt, 0, sizeof(int), c->stream));
-        if (launch_chemistry(c, c->stream, c->chem_dt, 0, (size_t)n, c->d_defer[cur], t == 3 ? 0 : (int)ceiling,
-                             c->d_defer[nxt], c->d_chemctl + nxt))
-          return 1;
-        cur = nxt;
-      }
+    // later tiers: the cells dropped by the previous launch(es), densely packed
+    int cur = 0;
+    long long ceiling = c->chem_b1;
+    size_t done = (size_t)c->chem_list0_done; // head of list 0 already restarted by the opening sample
+    for (int t = 1; t <= 3 && ceiling > 0; t++) {
+      int n = 0;
+      HIPCHK(c, hipMemcpyAsync(&n, c->d_chemctl + cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if ((size_t)n <= done) break;
+      const int nxt = cur ^ 1;
+      ceiling *= 8;
+      HIPCHK(c, hipMemsetAsync(c->d_chemctl + nxt, 0, sizeof(int), c->stream));
+      if (launch_chemistry(c, c->stream, c->chem_dt, done, (size_t)n - done, c->d_defer[cur], t == 3 ? 0 : (int)ceiling,
+                           c->d_defer[nxt], c->d_chemctl + nxt))
+        return 1;
+      cur = nxt;
+      done = 0;
     }
-    // the next pass's first ceiling from this pass's histogram (bucket b: sub-step counts in [2^(b-1), 2^b))
+    c->chem_sample = 0;
+    c->chem_list0_done = 0;
+    // the whole pass's histogram is the first guess for the next pass
     int hist[CHEM_HIST];
     HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    long long total = 0, acc = 0;
-    for (int b = 0; b < CHEM_HIST; b++) total += hist[b];
-    int b90 = 0, b999 = 0;
-    for (int b = 0; b < CHEM_HIST; b++) {
-      acc += hist[b];
-      if (acc * 10 < total * 9) b90 = b + 1;
-      if (acc * 1000 < total * 999) b999 = b + 1;
-    }
-    c->chem_b1 = (total > 0 && b999 >= b90 + 3) ? std::max(16, 1 << std::min(b90 + 1, 20)) : 0;
+    c->chem_b1_next = chemistry_ceiling(hist);
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
