@@ -1,0 +1,118 @@
+"""Randomised GPU-vs-oracle parity: meshes of odd shapes and sizes, sources anywhere (edges, corners, the same
+cell twice), any batch size, isothermal or heating, with or without the extra SEDs, Lyman-limit systems and
+clumping grids -- one pass and one global pass each, every array compared bit for bit.  The case list is seeded;
+C2R_FUZZ_CASES / C2R_FUZZ_SEED widen or move it."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def _tables(pkg, orc, multi):
+    t = pkg.RadiationTables.load()
+    with np.load(pkg.evolve.DEFAULT_TABLES) as z:
+        d = {k: z[k] for k in z.files}
+    if multi:
+        t.add_sed_file(GOLD / "rad_tables_pl_qpl.npz")
+        with np.load(GOLD / "rad_tables_pl_qpl.npz") as z:
+            d.update({k: z[k] for k in z.files})
+    return t, orc.Tables(d)
+
+
+def _case(rng):
+    mesh = tuple(int(x) for x in rng.choice([2, 3, 5, 8, 9, 12, 16, 21, 24, 30, 33, 40], size=3))
+    if rng.random() < 0.4:
+        mesh = (mesh[0],) * 3
+    return dict(mesh=mesh, nsrc=int(rng.integers(1, 7)), iso=bool(rng.random() < 0.5), multi=bool(rng.random() < 0.3),
+                lls=int(rng.integers(0, 3)), clump=bool(rng.random() < 0.3), batch=int(rng.integers(1, 9)),
+                opacity=float(rng.uniform(-4.5, -0.5)), seed=int(rng.integers(1 << 30)))
+
+
+def test_random_cases_vs_oracle(pkg, orc):
+    ncases = int(os.environ.get("C2R_FUZZ_CASES", "40"))
+    master = np.random.default_rng(int(os.environ.get("C2R_FUZZ_SEED", "20261004")))
+    hp = pkg.hostphys
+    cache = {}
+    for ic in range(ncases):
+        cs = _case(master)
+        rng = np.random.default_rng(cs["seed"])
+        n1, n2, n3 = cs["mesh"]
+        nc = n1 * n2 * n3
+        zred = 9.0
+        dr, vol = hp.test_grid(max(cs["mesh"]), zred)
+        ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.6, nc))
+        xn = np.minimum(0.999, 10.0 ** (cs["opacity"] + rng.uniform(-0.5, 0.5, nc)))   # neutral fraction
+        xh = np.concatenate([xn, 1.0 - xn])
+        xhe = np.concatenate([xn, 0.8 * (1.0 - xn), 0.2 * (1.0 - xn)])
+        temp = None if cs["iso"] else np.tile((1e4 * np.exp(rng.normal(0, 0.3, nc))).astype(np.float32), 3)
+        srcpos = np.stack([rng.integers(1, n + 1, size=cs["nsrc"]) for n in cs["mesh"]], axis=1).astype(np.int32)
+        if cs["nsrc"] > 1 and rng.random() < 0.3:
+            srcpos[1] = srcpos[0]                       # two sources in one cell
+        if rng.random() < 0.3:
+            srcpos[0] = (1, n2, 1)                      # a corner
+        flux = 10.0 ** rng.uniform(4.0, 7.5, cs["nsrc"])
+        pl = qpl = None
+        if cs["multi"]:
+            pl = np.where(rng.random(cs["nsrc"]) < 0.6, 10.0 ** rng.uniform(4.0, 7.0, cs["nsrc"]), 0.0)
+            qpl = np.where(rng.random(cs["nsrc"]) < 0.6, 10.0 ** rng.uniform(4.0, 7.0, cs["nsrc"]), 0.0)
+            flux = np.where(rng.random(cs["nsrc"]) < 0.8, flux, 0.0)
+        lls_grid = clump = None
+        coldensh_lls = None
+        if cs["lls"] == 1:
+            coldensh_lls = float(10.0 ** rng.uniform(15, 17))
+        elif cs["lls"] == 2:
+            lls_grid = (10.0 ** rng.uniform(15.0, 17.5, nc)).astype(np.float32)
+        if cs["clump"]:
+            clump = (1.0 + 5.0 * rng.random(nc)).astype(np.float32)
+        key = cs["multi"]
+        if key not in cache:
+            cache[key] = _tables(pkg, orc, cs["multi"])
+        t, T = cache[key]
+        mat = pkg.Material(ndens, xh, xhe, temp, cs["iso"], 1.0e4, 1.7, hp.reccoef(1.0e4), clumping_grid=clump,
+                           use_LLS=cs["lls"] > 0, coldensh_LLS=coldensh_lls or 0.0, LLS_grid=lls_grid)
+        grid = pkg.GridProps(cs["mesh"], dr, vol)
+        src = pkg.SourceProps(srcpos, flux, 1.0e48, NormFluxPL=pl, pl_S_star=1.5e48, NormFluxQPL=qpl, qpl_S_star=0.7e48)
+        cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+        e = pkg.HipEngine(cs["mesh"], 0)
+        e.set_tables(t)
+        e.set_step(mat, grid, cosmo)
+        e.set_sources(src)
+        e.upload_state(mat)
+        e.set_batch(cs["batch"])
+        e.begin_step()
+        e.set_rates_to_zero()
+        e.pass_sources(1, 1)
+        rates = e.download_rates()
+        cols = e.download_columns()
+        st = orc.Step(cs["mesh"], dr, vol, zred, hp.H0, hp.Omega0, cs["iso"], 1.0e4, 1.7, srcpos, flux, 1.0e48, ndens,
+                      hp.reccoef(1.0e4), normflux_pl=pl, normflux_qpl=qpl, pl_s_star=1.5e48, qpl_s_star=0.7e48,
+                      coldensh_lls=coldensh_lls, lls_grid=lls_grid, clumping_grid=clump)
+        s = orc.State(st, xh, xhe, temp)
+        orc.begin_step(s)
+        orc.pass_all_sources(T, st, s)
+        tag = (ic, cs)
+        assert rates["sum_nbox"] == int(s.c.sum_nbox), tag
+        assert np.array_equal(cols["coldensh_out"], s.coldensh_out), tag
+        assert np.array_equal(cols["coldenshe_out"], s.coldenshe_out), tag
+        assert np.array_equal(rates["phih_grid"], s.phih) and np.array_equal(rates["phihe_grid"], s.phihe), tag
+        if not cs["iso"]:
+            assert np.array_equal(rates["phiheat"], s.phiheat), tag
+        if s.photon_loss[0] > 0:
+            assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-12, tag
+        dt = float(10.0 ** rng.uniform(5, 7.3)) * hp.YEAR
+        conv = e.global_pass(dt)
+        assert conv == orc.global_pass(T, st, s, dt), tag
+        it = e.download_iter_state()
+        for k in ("xh_av", "xhe_av", "xh_intermed", "xhe_intermed"):
+            assert np.array_equal(it[k], getattr(s, k)), (k, tag)
+        if not cs["iso"]:
+            m2 = pkg.Material(None, np.empty(2 * nc), np.empty(3 * nc), np.empty(3 * nc, dtype=np.float32), False)
+            e.download_state(m2)
+            assert np.array_equal(m2.temperature_grid, s.temperature), tag
+        e.close()
