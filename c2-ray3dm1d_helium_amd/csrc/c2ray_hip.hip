@@ -1603,6 +1603,9 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
       S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
       for (int d = 0; d < 3; d++) { S.lo[d] = run[b].last_l[d]; S.hi[d] = run[b].last_r[d]; }
+      // a source whose while-test failed before the first sub-box (a mesh only two cells deep) traced nothing:
+      // an empty box, so that no cell passes the in-box test
+      if (run[b].nbox == 0) { S.lo[0] = 1; S.hi[0] = 0; }
       S.nflux = c->normflux[run[b].ns - 1];
       for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][run[b].ns - 1];
       S.slot = slot0 + b;
@@ -1628,6 +1631,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         std::vector<unsigned char> cov[3];
         const int tsz[3] = {8, 8, 4}, ntd[3] = {nt1, nt2, nt3};
         for (int b = 0; b < nb; b++) {
+          if (run[b].nbox == 0) continue;
           const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
           for (int d = 0; d < 3; d++) {
             cov[d].assign((size_t)ntd[d], 0);
@@ -1721,6 +1725,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     c->last_slot = slot0 + nb - 1;
     c->last_src = run[nb - 1].ns;
     for (int d = 0; d < 3; d++) { c->last_lo[d] = run[nb - 1].last_l[d]; c->last_hi[d] = run[nb - 1].last_r[d]; }
+    if (run[nb - 1].nbox == 0) { c->last_lo[0] = 1; c->last_hi[0] = 0; } // nothing traced: all columns read as 0
   }
   // a rank without sources of its own still owes the caller its slab events
   if (mine.empty())
