@@ -120,3 +120,44 @@ def test_random_cases_vs_oracle(pkg, orc):
             e.download_state(m2)
             assert np.array_equal(m2.temperature_grid, s.temperature), tag
         e.close()
+
+
+def test_random_whole_evolve3d_vs_oracle(pkg, orc):
+    """Whole evolve3D calls (all outer iterations, end-of-step copies, the heating pass's tiers from the second
+    iteration on) on random small boxes: iteration count, per-iteration non-converged counts and the final
+    state bit for bit against the oracle."""
+    ncases = int(os.environ.get("C2R_FUZZ_EVOLVE_CASES", "8"))
+    master = np.random.default_rng(int(os.environ.get("C2R_FUZZ_SEED", "20261004")) + 1)
+    hp = pkg.hostphys
+    t, T = _tables(pkg, orc, False)
+    for ic in range(ncases):
+        rng = np.random.default_rng(int(master.integers(1 << 30)))
+        mesh = tuple(int(x) for x in rng.choice([8, 11, 14, 16, 20], size=3))
+        iso = bool(rng.random() < 0.4)
+        nsrc = int(rng.integers(1, 4))
+        nc = mesh[0] * mesh[1] * mesh[2]
+        zred = 9.0
+        dr, vol = hp.test_grid(max(mesh), zred)
+        ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc)) * float(10.0 ** rng.uniform(0, 1.5))
+        xn = np.minimum(0.999, 10.0 ** (rng.uniform(-3, -0.3) + rng.uniform(-0.3, 0.3, nc)))
+        xh = np.concatenate([xn, 1.0 - xn])
+        xhe = np.concatenate([xn, 0.8 * (1.0 - xn), 0.2 * (1.0 - xn)])
+        temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.3, nc))).astype(np.float32), 3)
+        srcpos = np.stack([rng.integers(1, n + 1, size=nsrc) for n in mesh], axis=1).astype(np.int32)
+        flux = 10.0 ** rng.uniform(5.0, 7.0, nsrc)
+        dt = float(10.0 ** rng.uniform(5.5, 7.0)) * hp.YEAR
+        mat = pkg.Material(ndens, xh.copy(), xhe.copy(), None if temp is None else temp.copy(), iso, 1.0e4, 1.0, hp.reccoef(1.0e4))
+        grid = pkg.GridProps(mesh, dr, vol)
+        src = pkg.SourceProps(srcpos, flux, 1.0e48)
+        cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+        ev = pkg.Evolve(mesh, t, device=0)
+        niter = ev.evolve3D(0.0, dt, 0, mat, grid, src, cosmo)
+        st = orc.Step(mesh, dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens, hp.reccoef(1.0e4))
+        s = orc.State(st, xh, xhe, temp)
+        tag = (ic, mesh, iso, nsrc)
+        assert orc.evolve3d(T, st, s, dt) == niter, tag
+        assert ev.conv_flags == s.conv_flags, tag
+        assert np.array_equal(mat.xh, s.xh) and np.array_equal(mat.xhe, s.xhe), tag
+        if not iso:
+            assert np.array_equal(mat.temperature_grid, s.temperature), tag
+        ev.engine.close()
