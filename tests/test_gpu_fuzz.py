@@ -91,7 +91,12 @@ def test_random_cases_vs_oracle(pkg, orc):
         e.set_batch(cs["batch"])
         e.begin_step()
         e.set_rates_to_zero()
-        e.pass_sources(1, 1)
+        if rng.random() < 0.4:      # the slab-wise hand-over of the same pass
+            for sl in range(e.pass_sources_begin(1, 1, int(rng.integers(1, 9)))):
+                e.pass_wait_slab(sl)
+            e.pass_sources_end()
+        else:
+            e.pass_sources(1, 1)
         rates = e.download_rates()
         cols = e.download_columns()
         st = orc.Step(cs["mesh"], dr, vol, zred, hp.H0, hp.Omega0, cs["iso"], 1.0e4, 1.7, srcpos, flux, 1.0e48, ndens,
@@ -110,7 +115,13 @@ def test_random_cases_vs_oracle(pkg, orc):
         if s.photon_loss[0] > 0:
             assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-12, tag
         dt = float(10.0 ** rng.uniform(5, 7.3)) * hp.YEAR
-        conv = e.global_pass(dt)
+        if rng.random() < 0.4:      # the global pass in pieces
+            cut = int(rng.integers(0, nc + 1))
+            e.global_pass_cells(dt, 0, cut)
+            e.global_pass_cells(dt, cut, nc - cut)
+            conv = e.global_pass_finish()
+        else:
+            conv = e.global_pass(dt)
         assert conv == orc.global_pass(T, st, s, dt), tag
         it = e.download_iter_state()
         for k in ("xh_av", "xhe_av", "xh_intermed", "xhe_intermed"):
