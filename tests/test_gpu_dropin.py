@@ -84,3 +84,28 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     pa, pb = np.where(fin, pa, 0.0), np.where(fin, pb, 0.0)
     scale = np.maximum(np.abs(pa), np.abs(pa[:, 1:2]) * 1e-3)
     assert np.all(np.abs(pb - pa) <= 2.5e-3 * scale), np.max(np.abs(pb - pa) / scale)
+
+
+def test_random_source_lists_through_both_binaries():
+    """Seeded random source lists (1-6 sources anywhere on the 16^3 mesh, 1e53-1e55 photons/s, isothermal or
+    heating) through the reference binary and the reference driver + HIP evolve3D: byte-identical output files.
+    C2R_DROPIN_FUZZ_CASES widens it."""
+    import os
+    import numpy as np
+    import refrun
+    ref, hip = refrun.ref_binary(16, "test"), refrun.ref_binary(16, "hip")
+    if not ref.exists() or not hip.exists():
+        pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
+    rng = np.random.default_rng(int(os.environ.get("C2R_FUZZ_SEED", "20261004")))
+    for ic in range(int(os.environ.get("C2R_DROPIN_FUZZ_CASES", "2"))):
+        nsrc = int(rng.integers(1, 7))
+        sources = [(int(rng.integers(1, 17)), int(rng.integers(1, 17)), int(rng.integers(1, 17)), float(10.0 ** rng.uniform(53, 55)))
+                   for _ in range(nsrc)]
+        iso = bool(rng.random() < 0.5)
+        r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_fz_ref_{ic}")
+        r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="hip", name=f"dropin_fz_hip_{ic}")
+        files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
+        assert len(files) >= 15, files
+        for f in files:
+            assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), (ic, sources, iso, f)
+        assert refrun.parse_log(r1) == refrun.parse_log(r2), (ic, sources, iso)
