@@ -35,6 +35,12 @@
 
 #define C2R_F(x) ((double)(x##f))
 
+#if !defined(C2R_USE_PLATFORM_LIBM)
+#define C2R_LOGTAB_DEFAULT ::c2r::gm::log_table()
+#else
+#define C2R_LOGTAB_DEFAULT nullptr
+#endif
+
 namespace c2r {
 
 constexpr int NFREQ = 47;    // radiation_sizes.f90:22
@@ -127,7 +133,8 @@ C2R_HD double dmin(double a, double b) { return a < b ? a : b; }
 // 3 FP64 instructions instead of the ~12 (one quarter-rate) of the gfx950 division sequence.
 struct Recip {
   double b, y;
-  bool ok;
+  bool ok;     // div_recip's proviso on b
+  bool ok_big; // ok, and b >= 1: then a quotient's own magnitude tells whether anything underflowed (div_by_vol)
 };
 C2R_HD Recip make_recip(double b) {
   Recip R;
@@ -136,6 +143,7 @@ C2R_HD Recip make_recip(double b) {
   const uint64_t u = __builtin_bit_cast(uint64_t, b);
   const int e = (int)((u >> 52) & 0x7ff);
   R.ok = (u & 0x000FFFFFFFFFFFFFULL) != 0x000FFFFFFFFFFFFFULL && e > 1023 - 400 && e < 1023 + 400;
+  R.ok_big = R.ok && e >= 1023 && (u >> 63) == 0;
   return R;
 }
 C2R_HD double div_recip(double a, const Recip &R) {
@@ -400,8 +408,16 @@ struct TauPos {
   int ipos;
   double residual;
 };
-C2R_HD TauPos tau_table_position(double tau) {
-  double lt = C2R_MATH_LOG10N(dmax(1.0e-20, tau)); // positive, normal and finite by construction
+#if defined(__HIP_DEVICE_COMPILE__)
+// max / min of two numbers neither of which is a NaN: one instruction
+C2R_HD double dmax_num(double a, double b) { return __builtin_fmax(a, b); }
+C2R_HD double dmin_num(double a, double b) { return __builtin_fmin(a, b); }
+#else
+C2R_HD double dmax_num(double a, double b) { return a > b ? a : b; }
+C2R_HD double dmin_num(double a, double b) { return a < b ? a : b; }
+#endif
+// the position that belongs to lt = log10(max(1e-20, tau))
+C2R_HD TauPos table_position_of_log(double lt) {
   // (lt - minlogtau)/dlogtau, correctly rounded through the constant's reciprocal (div_recip);
   // the numerator lies in [0, 24.5], dlogtau = 0x1.89374bc6a7efap-7
   const double num = lt - minlogtau;
@@ -409,16 +425,46 @@ C2R_HD TauPos tau_table_position(double tau) {
   const double q0 = num * rdl;
   const double quo = __builtin_fma(__builtin_fma(-dlogtau, q0, num), rdl, q0);
   // max(0, .) of the reference (:299) cannot bind: lt >= log10(1e-20) makes 1 + quo >= 1 - 1e-12
-  double odpos = dmin((double)NTAU, 1.0 + quo);
+  const double odpos = dmin_num((double)NTAU, 1.0 + quo);
   TauPos p;
   p.ipos = (int)odpos;
   p.residual = odpos - (double)p.ipos;
   return p;
 }
+#if !defined(C2R_USE_PLATFORM_LIBM)
+// `logtab`: the (invc, logc) table of the bit-exact log, wherever the caller keeps it (k_rates: LDS)
+C2R_HD TauPos tau_table_position(double tau, const double *logtab = C2R_LOGTAB_DEFAULT) {
+  const double x = dmax_num(tau, 1.0e-20); // positive, normal and finite by construction
+  return table_position_of_log(gm::log10_norm(x, logtab));
+}
+// Two optical depths at once (the two faces of a cell): both table-path evaluations of the log run as one
+// straight line -- their loads and dependent fma chains overlap --, and the polynomial path of __log_fma
+// (arguments near 1: one in ten, spatially coherent) is entered only when some lane of the wave needs it.
+C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab, TauPos &pa, TauPos &pb) {
+  const gm::Log10Arg a = gm::log10_split(dmax_num(tau_a, 1.0e-20)), b = gm::log10_split(dmax_num(tau_b, 1.0e-20));
+  double lga = gm::log_table_path(a, logtab), lgb = gm::log_table_path(b, logtab);
+  const bool na = gm::log10_near1(a), nb = gm::log10_near1(b);
+  if (na || nb) {
+    if (na) lga = gm::log_near1(gm::log10_arg_value(a));
+    if (nb) lgb = gm::log_near1(gm::log10_arg_value(b));
+  }
+  pa = table_position_of_log(gm::log10_finish(a, lga));
+  pb = table_position_of_log(gm::log10_finish(b, lgb));
+}
+#else
+C2R_HD TauPos tau_table_position(double tau, const double * = nullptr) {
+  return table_position_of_log(C2R_MATH_LOG10N(dmax(1.0e-20, tau)));
+}
+C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *, TauPos &pa, TauPos &pb) {
+  pa = tau_table_position(tau_a);
+  pb = tau_table_position(tau_b);
+}
+#endif
 // :310-326; col points at row 0 of a column with pitch NTAUP whose row 2001 duplicates row 2000,
 // so that ipos_p1 = min(NumTau, ipos+1) needs no clamp: (c[2001]-c[2000])*residual == 0 exactly.
 C2R_HD double read_table(const double *col, const TauPos &p) {
-  double a = col[p.ipos], b = col[p.ipos + 1];
+  const double *e = col + (unsigned)p.ipos;
+  double a = e[0], b = e[1];
   return a + (b - a) * p.residual;
 }
 
@@ -447,6 +493,232 @@ C2R_HD Ricotti ricotti_parameters(double i_state) {
   return R;
 }
 
+// What stays the same for every band of one (cell, source) pair.
+struct CellSrc {
+  double cin_HI, cin_HeI, cin_HeII, cout_HI, cout_HeI, cout_HeII;
+  double cell_HI, cell_HeI, cell_HeII; // column of the cell itself
+  double NFlux;
+  Recip rvol;      // the shell volume vol_ph as divisor
+  bool recip_safe; // the sums of scale_int2/3 lie where recip_nr is exact (see there)
+};
+
+// RN(1/x) for the denominators of scale_int2 / scale_int3: the instruction sequence the compiler emits for 1.0/x
+// (v_rcp_f64 seed, two Newton steps, the residual correction) without the operand scaling (v_div_scale) and the
+// special-case patch-up (v_div_fixup) around it, which do nothing for 2^-600 < x < 2^600: 7 instructions instead
+// of 11, same bits (tests/test_gpu_math.py compares it with the division on 4e6 operands).  The caller
+// guarantees the range: CellSrc::recip_safe (cell columns within 2^+-300, cross sections within [2^-100, 2^-30],
+// checked once per table set on the host).
+C2R_HD double recip_nr(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(e, y, y);
+#else
+  return 1.0 / x;
+#endif
+}
+C2R_HD bool column_in_recip_range(double c) { return c >= 0x1p-300 && c <= 0x1p300; }
+
+// a/vol for up to three numerators of one band at once: Markstein's sequence (div_recip) unconditionally, one
+// comparison per quotient as the guard, and the plain divisions only where a guard fails for a non-zero
+// numerator.  With the divisor in [1, 2^400] (Recip::ok_big) a quotient of magnitude >= 2^-900 proves that
+// nothing under- or overflowed on the way; a zero numerator gives a zero quotient either way.
+template <int N>
+C2R_HD void div_by_vol(const Recip &R, const double (&a)[N], double (&d)[N]) {
+  double q[N];
+  bool doubt = !R.ok_big;
+#pragma unroll
+  for (int n = 0; n < N; n++) {
+    q[n] = a[n] * R.y;
+    d[n] = __builtin_fma(__builtin_fma(-R.b, q[n], a[n]), R.y, q[n]);
+    doubt = doubt || !(fabs(q[n]) >= 0x1p-900);
+  }
+  if (doubt) {
+    bool redo = !R.ok_big;
+#pragma unroll
+    for (int n = 0; n < N; n++) redo = redo || (!(fabs(q[n]) >= 0x1p-900) && a[n] != 0.0);
+    if (redo) {
+#pragma unroll
+      for (int n = 0; n < N; n++) d[n] = a[n] / R.b;
+    }
+  }
+}
+
+// sums one SED's lookuptable calls carry from band to band
+struct SedSums {
+  double photo_HI, photo_HeI, photo_HeII, photo_out;
+  double f_heat, f_ion_HI, f_ion_HeI, df_ion_HI, df_ion_HeI;
+};
+
+// One frequency band of photo_lookuptable (radiation_photoionrates.f90:331-464) + heat_lookuptable (:470-779) +
+// scale_int2/3 (:787-823).  CLS = 0: the band below the He I threshold (HI only), 1: bands NumBndin1+1 ..
+// +NumBndin2 (HI and HeI), 2: the bands above the He II threshold (all three species).  The cross sections of
+// species that cannot absorb in a band are exactly 0 (radiation_sizes.f90:382-383, :405; checked when the
+// tables are set), so their terms -- x*0 + ... with finite x -- are left out: the sums keep their bits.
+template <bool HEAT, int CLS>
+C2R_HD void band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
+                       const double *heat_thin, const double *logtab, int b, const CellSrc &c, const Ricotti &ric,
+                       SedSums &o) {
+  const double NFlux = c.NFlux;
+  const double sHI = bd.sigma_HI[b];
+  double sHeI = 0.0, sHeII = 0.0;
+  double tau_in = c.cin_HI * sHI, tau_out = c.cout_HI * sHI;
+  if (CLS >= 1) {
+    sHeI = bd.sigma_HeI[b];
+    tau_in = tau_in + c.cin_HeI * sHeI;
+    tau_out = tau_out + c.cout_HeI * sHeI;
+  }
+  if (CLS >= 2) {
+    sHeII = bd.sigma_HeII[b];
+    tau_in = tau_in + c.cin_HeII * sHeII;
+    tau_out = tau_out + c.cout_HeII * sHeII;
+  }
+  const double dtau = tau_out - tau_in;
+  const bool thick = fabs(dtau) > tau_photo_limit;
+  const bool hthick = fabs(dtau) > tau_heat_limit;
+  // both positions always: an optically thin band (no use for pout) is rare, and one straight line for the
+  // two logs is worth more than skipping one of them now and then
+  TauPos pin, pout;
+  tau_table_positions(tau_in, tau_out, logtab, pin, pout);
+
+  // species split of this band (scale_int2 / scale_int3)
+  double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
+  if (CLS == 1) {
+    const double tH = sHI * c.cell_HI, tHe = sHeI * c.cell_HeI;
+    const double den = tH + tHe;
+    const double forscaleing = c.recip_safe ? recip_nr(den) : 1.0 / den;
+    sc_HI = tH * forscaleing;
+    sc_HeI = tHe * forscaleing;
+  } else if (CLS == 2) {
+    const double tH = sHI * c.cell_HI, tHe = sHeI * c.cell_HeI, tHe2 = sHeII * c.cell_HeII;
+    const double den = tH + tHe + tHe2;
+    const double forscaleing = c.recip_safe ? recip_nr(den) : 1.0 / den;
+    sc_HI = tH * forscaleing;
+    sc_HeI = tHe * forscaleing;
+    sc_HeII = tHe2 * forscaleing;
+  }
+
+  // photo_lookuptable body
+  {
+    const double *tk = photo_thick + (size_t)b * NTAUP;
+    double phi_in, phi_out, phi_all;
+    if (thick) {
+      const double t_in = read_table(tk, pin), t_out = read_table(tk, pout);
+      phi_in = NFlux * t_in;
+      phi_out = NFlux * t_out;
+      phi_all = phi_in - phi_out;
+    } else {
+      const double t_in = read_table(tk, pin), t_thin = read_table(photo_thin + (size_t)b * NTAUP, pin);
+      phi_in = NFlux * t_in;
+      phi_all = NFlux * dtau * t_thin;
+      phi_out = phi_in - phi_all;
+    }
+    o.photo_out = o.photo_out + phi_out;
+    if (CLS == 0) {
+      const double a[1] = {phi_all};
+      double d[1];
+      div_by_vol<1>(c.rvol, a, d);
+      o.photo_HI = o.photo_HI + d[0];
+    } else if (CLS == 1) {
+      const double a[2] = {sc_HI * phi_all, sc_HeI * phi_all};
+      double d[2];
+      div_by_vol<2>(c.rvol, a, d);
+      o.photo_HI = o.photo_HI + d[0];
+      o.photo_HeI = o.photo_HeI + d[1];
+    } else {
+      const double a[3] = {sc_HI * phi_all, sc_HeI * phi_all, sc_HeII * phi_all};
+      double d[3];
+      div_by_vol<3>(c.rvol, a, d);
+      o.photo_HI = o.photo_HI + d[0];
+      o.photo_HeI = o.photo_HeI + d[1];
+      o.photo_HeII = o.photo_HeII + d[2];
+    }
+  }
+
+  if (HEAT) {
+    const double *y1R = ric.y1R, *y2R = ric.y2R;
+    double df_heat;
+    if (CLS == 0) {
+      const double *tk = heat_thick + (size_t)b * NTAUP;
+      double a[1];
+      if (hthick) {
+        const double in_HI = NFlux * read_table(tk, pin), out_HI = NFlux * read_table(tk, pout);
+        a[0] = in_HI - out_HI;
+      } else {
+        a[0] = NFlux * (c.cell_HI * sHI) * read_table(heat_thin + (size_t)b * NTAUP, pin);
+      }
+      double h[1];
+      div_by_vol<1>(c.rvol, a, h);
+      df_heat = h[0];
+    } else if (CLS == 1) {
+      const int cH = 2 * (b + 1) - NB1 - 1 - 1; // 0-based heating column of (band, HI)
+      const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP;
+      double a[2];
+      if (hthick) {
+        const double t0 = read_table(tkH, pin), t1 = read_table(tkHe, pin);
+        const double u0 = read_table(tkH, pout), u1 = read_table(tkHe, pout);
+        const double in_HI = NFlux * t0, in_HeI = NFlux * t1;
+        const double out_HI = NFlux * u0, out_HeI = NFlux * u1;
+        a[0] = sc_HI * (in_HI - out_HI);
+        a[1] = sc_HeI * (in_HeI - out_HeI);
+      } else {
+        const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
+        a[0] = NFlux * (c.cell_HI * sHI) * read_table(tnH, pin);
+        a[1] = NFlux * (c.cell_HeI * sHeI) * read_table(tnHe, pin);
+      }
+      double h[2];
+      div_by_vol<2>(c.rvol, a, h);
+      const double h_HI = h[0], h_HeI = h[1];
+      df_heat = h_HI + h_HeI;
+      const int q = b - 1; // f arrays are dimension(2:47)
+      const double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI;
+      const double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
+      const double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
+      const double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
+      o.df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
+      o.df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
+      df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+    } else {
+      const int cH = 3 * (b + 1) - NB2 - NB1 * 2 - 2 - 1;
+      const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP, *tkHe2 = tkHe + NTAUP;
+      double a[3];
+      if (hthick) {
+        const double t0 = read_table(tkH, pin), t1 = read_table(tkHe, pin), t2 = read_table(tkHe2, pin);
+        const double u0 = read_table(tkH, pout), u1 = read_table(tkHe, pout), u2 = read_table(tkHe2, pout);
+        const double in_HI = NFlux * t0, in_HeI = NFlux * t1, in_HeII = NFlux * t2;
+        const double out_HI = NFlux * u0, out_HeI = NFlux * u1, out_HeII = NFlux * u2;
+        a[0] = sc_HI * (in_HI - out_HI);
+        a[1] = sc_HeI * (in_HeI - out_HeI);
+        a[2] = sc_HeII * (in_HeII - out_HeII);
+      } else {
+        const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
+        a[0] = NFlux * (c.cell_HI * sHI) * read_table(tnH, pin);
+        a[1] = NFlux * (c.cell_HeI * sHeI) * read_table(tnHe, pin);
+        a[2] = NFlux * (c.cell_HeII * sHeII) * read_table(tnHe2, pin);
+      }
+      double h[3];
+      div_by_vol<3>(c.rvol, a, h);
+      const double h_HI = h[0], h_HeI = h[1], h_HeII = h[2];
+      df_heat = h_HI + h_HeI + h_HeII;
+      const int q = b - 1;
+      const double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI + bd.f1ion_HeII[q] * h_HeII;
+      const double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
+      const double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
+      const double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
+      o.df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
+      o.df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
+      df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+    }
+    o.f_heat = o.f_heat + df_heat;
+    o.f_ion_HI = o.f_ion_HI + o.df_ion_HI;
+    o.f_ion_HeI = o.f_ion_HeI + o.df_ion_HeI;
+  }
+}
+
 // what one photo_lookuptable + heat_lookuptable pair of calls returns for one SED (before the sums of
 // radiation_photoionrates.f90:178-262 put them together)
 struct SedAcc {
@@ -455,160 +727,41 @@ struct SedAcc {
 };
 
 // radiation_photoionrates.f90:108-277 photoion_rates with its callees photo_lookuptable (:331-464),
-// heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands.
-// Band-local quantities are computed in the reference's order; sums over bands run b = 1..bb_upper
-// as in the reference.  HEAT selects the non-isothermal path.
+// heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands
+// [blo, bhi) (0-based), in three stretches by band class; every sum runs in band order as in the reference.
+// HEAT selects the non-isothermal path.  `logtab`: see tau_table_position.
 template <bool HEAT>
 C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                       const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
                       double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                      double NFlux, const Ricotti &ric, SedAcc &o) {
-  o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
-  o.photo_out = 0.0;
-  o.f_heat = o.f_ion_HI = o.f_ion_HeI = 0.0;
+                      double NFlux, const Ricotti &ric, SedAcc &out, const double *logtab) {
+  out.photo_HI = out.photo_HeI = out.photo_HeII = 0.0;
+  out.photo_out = 0.0;
+  out.f_heat = out.f_ion_HI = out.f_ion_HeI = 0.0;
   if (!(NFlux > 0.0)) return;
-  const Recip rvol = make_recip(vol);
-  const double cell_HI = cout_HI - cin_HI;
-  const double cell_HeI = cout_HeI - cin_HeI;
-  const double cell_HeII = cout_HeII - cin_HeII;
-
-  double f_heat = 0.0, f_ion_HI = 0.0, f_ion_HeI = 0.0;
-  double df_ion_HI = 0.0, df_ion_HeI = 0.0;
-  const double *y1R = ric.y1R, *y2R = ric.y2R;
-
-  for (int b = blo; b < bhi; b++) { // b is 0-based here; reference band = b+1
-    const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
-    const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
-    const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
-    const TauPos pin = tau_table_position(tau_in);
-    const double dtau = tau_out - tau_in;
-    const bool thick = fabs(dtau) > tau_photo_limit;
-    const bool hthick = fabs(dtau) > tau_heat_limit;
-    TauPos pout;
-    if (thick || (HEAT && hthick)) pout = tau_table_position(tau_out);
-    else { pout.ipos = 0; pout.residual = 0.0; }
-
-    // species split of this band (scale_int2 / scale_int3)
-    double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
-    if (b >= NB1 && b < NB1 + NB2) {
-      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI);
-      sc_HI = sHI * cell_HI * forscaleing;
-      sc_HeI = sHeI * cell_HeI * forscaleing;
-    } else if (b >= NB1 + NB2) {
-      double forscaleing = 1.0 / (sHI * cell_HI + sHeI * cell_HeI + sHeII * cell_HeII);
-      sc_HI = cell_HI * sHI * forscaleing;
-      sc_HeI = cell_HeI * sHeI * forscaleing;
-      sc_HeII = cell_HeII * sHeII * forscaleing;
-    }
-
-    // photo_lookuptable body
-    {
-      const double *tk = photo_thick + (size_t)b * NTAUP;
-      double phi_in = NFlux * read_table(tk, pin);
-      double phi_out, phi_all;
-      if (thick) {
-        phi_out = NFlux * read_table(tk, pout);
-        phi_all = phi_in - phi_out;
-      } else {
-        phi_all = NFlux * dtau * read_table(photo_thin + (size_t)b * NTAUP, pin);
-        phi_out = phi_in - phi_all;
-      }
-      o.photo_out = o.photo_out + phi_out;
-      if (b < NB1) {
-        o.photo_HI = o.photo_HI + div_recip(phi_all, rvol);
-      } else if (b < NB1 + NB2) {
-        o.photo_HI = o.photo_HI + div_recip(sc_HI * phi_all, rvol);
-        o.photo_HeI = o.photo_HeI + div_recip(sc_HeI * phi_all, rvol);
-      } else {
-        o.photo_HI = o.photo_HI + div_recip(sc_HI * phi_all, rvol);
-        o.photo_HeI = o.photo_HeI + div_recip(sc_HeI * phi_all, rvol);
-        o.photo_HeII = o.photo_HeII + div_recip(sc_HeII * phi_all, rvol);
-      }
-    }
-
-    if (HEAT) {
-      double df_heat;
-      if (b < NB1) {
-        const double *tk = heat_thick + (size_t)b * NTAUP;
-        double in_HI = NFlux * read_table(tk, pin);
-        double h_HI;
-        if (hthick) {
-          double out_HI = NFlux * read_table(tk, pout);
-          h_HI = div_recip(in_HI - out_HI, rvol);
-        } else {
-          h_HI = NFlux * (cell_HI * sHI) * read_table(heat_thin + (size_t)b * NTAUP, pin);
-          h_HI = div_recip(h_HI, rvol);
-        }
-        df_heat = h_HI;
-      } else if (b < NB1 + NB2) {
-        const int cH = 2 * (b + 1) - NB1 - 1 - 1; // 0-based heating column of (band, HI)
-        const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP;
-        double in_HI = NFlux * read_table(tkH, pin);
-        double in_HeI = NFlux * read_table(tkHe, pin);
-        double h_HI, h_HeI;
-        if (hthick) {
-          double out_HI = NFlux * read_table(tkH, pout);
-          h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
-          double out_HeI = NFlux * read_table(tkHe, pout);
-          h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
-        } else {
-          const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
-          h_HI = NFlux * (cell_HI * sHI) * read_table(tnH, pin);
-          h_HI = div_recip(h_HI, rvol);
-          h_HeI = NFlux * (cell_HeI * sHeI) * read_table(tnHe, pin);
-          h_HeI = div_recip(h_HeI, rvol);
-        }
-        df_heat = h_HI + h_HeI;
-        const int q = b - 1; // f arrays are dimension(2:47)
-        double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI;
-        double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
-        double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
-        double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
-        df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
-        df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
-        df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
-      } else {
-        const int cH = 3 * (b + 1) - NB2 - NB1 * 2 - 2 - 1;
-        const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP, *tkHe2 = tkHe + NTAUP;
-        double in_HI = NFlux * read_table(tkH, pin);
-        double in_HeI = NFlux * read_table(tkHe, pin);
-        double in_HeII = NFlux * read_table(tkHe2, pin);
-        double h_HI, h_HeI, h_HeII;
-        if (hthick) {
-          double out_HI = NFlux * read_table(tkH, pout);
-          h_HI = div_recip(sc_HI * (in_HI - out_HI), rvol);
-          double out_HeI = NFlux * read_table(tkHe, pout);
-          h_HeI = div_recip(sc_HeI * (in_HeI - out_HeI), rvol);
-          double out_HeII = NFlux * read_table(tkHe2, pout);
-          h_HeII = div_recip(sc_HeII * (in_HeII - out_HeII), rvol);
-        } else {
-          const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
-          h_HI = NFlux * (cell_HI * sHI) * read_table(tnH, pin);
-          h_HI = div_recip(h_HI, rvol);
-          h_HeI = NFlux * (cell_HeI * sHeI) * read_table(tnHe, pin);
-          h_HeI = div_recip(h_HeI, rvol);
-          h_HeII = NFlux * (cell_HeII * sHeII) * read_table(tnHe2, pin);
-          h_HeII = div_recip(h_HeII, rvol);
-        }
-        df_heat = h_HI + h_HeI + h_HeII;
-        const int q = b - 1;
-        double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI + bd.f1ion_HeII[q] * h_HeII;
-        double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
-        double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
-        double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
-        df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
-        df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
-        df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
-      }
-      f_heat = f_heat + df_heat;
-      f_ion_HI = f_ion_HI + df_ion_HI;
-      f_ion_HeI = f_ion_HeI + df_ion_HeI;
-    }
-  }
+  CellSrc c;
+  c.cin_HI = cin_HI; c.cin_HeI = cin_HeI; c.cin_HeII = cin_HeII;
+  c.cout_HI = cout_HI; c.cout_HeI = cout_HeI; c.cout_HeII = cout_HeII;
+  c.cell_HI = cout_HI - cin_HI;
+  c.cell_HeI = cout_HeI - cin_HeI;
+  c.cell_HeII = cout_HeII - cin_HeII;
+  c.NFlux = NFlux;
+  c.rvol = make_recip(vol);
+  c.recip_safe = column_in_recip_range(c.cell_HI) && column_in_recip_range(c.cell_HeI) && column_in_recip_range(c.cell_HeII);
+  SedSums o = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int e0 = bhi < NB1 ? bhi : NB1, e1 = bhi < NB1 + NB2 ? bhi : NB1 + NB2;
+  int b = blo;
+  for (; b < e0; b++) band_rates<HEAT, 0>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, b, c, ric, o);
+  for (; b < e1; b++) band_rates<HEAT, 1>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, b, c, ric, o);
+  for (; b < bhi; b++) band_rates<HEAT, 2>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, b, c, ric, o);
+  out.photo_HI = o.photo_HI;
+  out.photo_HeI = o.photo_HeI;
+  out.photo_HeII = o.photo_HeII;
+  out.photo_out = o.photo_out;
   if (HEAT) {
-    o.f_heat = f_heat;
-    o.f_ion_HI = f_ion_HI;
-    o.f_ion_HeI = f_ion_HeI;
+    out.f_heat = o.f_heat;
+    out.f_ion_HI = o.f_ion_HI;
+    out.f_ion_HeI = o.f_ion_HeI;
   }
 }
 
@@ -618,10 +771,10 @@ template <bool HEAT>
 C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                            const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
                            double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                           double NFlux, const Ricotti &ric, PhotoOut &o) {
+                           double NFlux, const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT) {
   SedAcc a;
   sed_rates<HEAT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
-                  cin_HeII, cout_HeII, vol, NFlux, ric, a);
+                  cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab);
   o.photo_HI = a.photo_HI;
   o.photo_HeI = a.photo_HeI;
   o.photo_HeII = a.photo_HeII;
@@ -649,7 +802,7 @@ struct SedSet {
 template <bool HEAT>
 C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                                  double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
-                                 const Ricotti &ric, PhotoOut &o) {
+                                 const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
@@ -662,7 +815,7 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
     act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
     if (act[s])
       sed_rates<HEAT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
-                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s]);
+                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab);
   }
   // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
   for (int s = 0; s < NSED; s++) {

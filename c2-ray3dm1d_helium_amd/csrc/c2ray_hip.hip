@@ -384,6 +384,11 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
   // busy for a box of width w instead of w/(w+63).  Loads are 16 segments of 32 B; the kernel is ALU-bound.
   // `tiles`, when given, lists the tiles that intersect a sub-box of the batch (built on the host): the
   // launch then holds only blocks with work, which keeps enough heavy waves resident per SIMD.
+  // the (invc, logc) table of the bit-exact log (2 KB) in LDS: two gathers per band iteration that no longer
+  // queue behind the photo-table gathers in the vector memory path
+  __shared__ double s_logtab[256];
+  s_logtab[threadIdx.x] = gm::log_table()[threadIdx.x];
+  __syncthreads();
   const int ti = (g.n1 + 7) >> 3, tj = (g.n2 + 7) >> 3;
   const int tile = tiles ? tiles[tile_base + blockIdx.x] : tile_base + (int)blockIdx.x;
   const int bi = tile % ti, bj = (tile / ti) % tj, bk = tile / (ti * tj);
@@ -433,10 +438,10 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
       PhotoOut o;
       if (MULTI) {
         const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o);
+        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab);
       } else {
         photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
-                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o);
+                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab);
       }
       a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
       a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);

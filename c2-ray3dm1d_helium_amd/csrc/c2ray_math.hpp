@@ -49,6 +49,18 @@ namespace gm {
 C2R_MHD uint64_t asuint64(double x) { return __builtin_bit_cast(uint64_t, x); }
 C2R_MHD double asdouble(uint64_t u) { return __builtin_bit_cast(double, u); }
 C2R_MHD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// a*k + c for two literal constants k and c.  Inside a divergent branch the compiler turns such an fma into
+// "copy c, then v_fmac" (one extra VALU instruction per polynomial coefficient pair); spelled out, it is the
+// three-address v_fma_f64 with k in scalar registers and c in a vector register that lives across the loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_kc(double a, double k, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+  return d;
+}
+#else
+C2R_MHD double fma_kc(double a, double k, double c) { return __builtin_fma(a, k, c); }
+#endif
 
 // ---- log: __log_fma ---------------------------------------------------------------------------
 // the branch of __log_fma for 1 - 0x1p-4 <= x < 1 + 0x1.09p-4 (precondition)
@@ -57,10 +69,10 @@ C2R_MHD double log_near1(double x) {
   // (glibc returns 0 for x == 1 up front; with r == 0 every term below is +0 in round-to-nearest,
   // so the shortcut changes nothing and is left out)
   const double r = x - 1.0;
-  const double u1 = fma_(r, B[2], B[1]);
-  const double u2 = fma_(r, B[5], B[4]);
+  const double u1 = fma_kc(r, B[2], B[1]);
+  const double u2 = fma_kc(r, B[5], B[4]);
   const double r2 = r * r;
-  const double u3 = fma_(r, B[8], B[7]);
+  const double u3 = fma_kc(r, B[8], B[7]);
   const double v1 = fma_(r2, B[3], u1);
   const double v2 = fma_(r2, B[6], u2);
   const double r3 = r * r2;
@@ -136,50 +148,71 @@ C2R_MHD double log10_(double x) {
 // temperatures): the same operations as log10_/log_core, with the 64-bit integer bookkeeping done
 // on the high 32-bit word (every constant involved has a zero low word, so this is exact) and
 // without the out-of-domain branch.  Bit-identical to log10_ (tests/test_math_host.py).
-// log10_norm: the caller guarantees a positive, normal, finite argument (tau_table_position passes
-// max(1e-20, tau)); log10_pos adds the check and falls back to log10_.
-C2R_MHD double log10_norm(double x) {
+// The routine comes in pieces so that a caller with two arguments (the optical depths at the two faces of a
+// cell) can run both table-path evaluations as one straight line -- their table loads and dependent fma chains
+// overlap -- and visit the polynomial path of __log_fma (arguments within [1-2^-4, 1+0x1.09p-4), one in ten)
+// only when some lane needs it.
+struct Log10Arg {
+  uint32_t hx, lo; // x' = x scaled by a power of two into [0.5, 2): high and low word
+  int ky;          // the power of two taken out (k + i of e_log10.c)
+};
+C2R_MHD Log10Arg log10_split(double x) { // x positive, normal, finite
   const uint64_t ix = asuint64(x);
-  const uint32_t hi = (uint32_t)(ix >> 32), lo = (uint32_t)ix;
+  const uint32_t hi = (uint32_t)(ix >> 32);
+  Log10Arg a;
+  a.lo = (uint32_t)ix;
+  const int k = (int)(hi >> 20) - 1023;
+  const int i = (int)((uint32_t)k >> 31);
+  a.hx = (hi & 0x000FFFFFu) | ((uint32_t)(0x3ff - i) << 20);
+  a.ky = k + i;
+  return a;
+}
+C2R_MHD bool log10_near1(const Log10Arg &a) { return a.hx - 0x3FEE0000u < 0x00030900u; }
+C2R_MHD double log10_arg_value(const Log10Arg &a) { return asdouble(((uint64_t)a.hx << 32) | a.lo); }
+// the table path of __log_fma on x'; `tab` = log_tab (invc, logc pairs), wherever the caller keeps it
+C2R_MHD double log_table_path(const Log10Arg &a, const double *tab) {
+  const double *H = GMT(log_hdr);
+  const double Ln2hi = H[0], Ln2lo = H[1];
+  const double *A = H + 2;
+  const uint32_t th = a.hx - 0x3FE60000u;
+  const int i2 = (int)((th >> 13) & 127u);
+  const int k2 = (int)th >> 20;
+  const uint32_t izh = a.hx - (th & 0xFFF00000u);
+  const double z = asdouble(((uint64_t)izh << 32) | a.lo);
+  const double invc = tab[2 * i2], logc = tab[2 * i2 + 1];
+  const double kd = (double)k2;
+  const double r = fma_(z, invc, -1.0);
+  const double w = fma_(kd, Ln2hi, logc);
+  const double t1 = fma_kc(r, A[2], A[1]);
+  const double hi_ = r + w;
+  const double r2 = r * r;
+  double lo_ = (w - hi_) + r;
+  lo_ = fma_(kd, Ln2lo, lo_);
+  const double r3 = r * r2;
+  const double t2 = fma_kc(r, A[4], A[3]);
+  const double s_ = fma_(r2, A[0], lo_);
+  const double p_ = fma_(t2, r2, t1);
+  const double q_ = fma_(r3, p_, s_);
+  return q_ + hi_;
+}
+// __ieee754_log10's tail: log10(x) from log(x') and the power of two
+C2R_MHD double log10_finish(const Log10Arg &a, double lg) {
   const double ivln10 = asdouble(0x3FDBCB7B1526E50EULL);
   const double log10_2hi = asdouble(0x3FD34413509F6000ULL);
   const double log10_2lo = asdouble(0x3D59FEF311F12B36ULL);
-  const int k = (int)(hi >> 20) - 1023;
-  const int i = (int)((uint32_t)k >> 31);
-  const uint32_t hx = (hi & 0x000FFFFFu) | ((uint32_t)(0x3ff - i) << 20);
-  const double y = (double)(k + i);
-  double lg;
-  const double *H = GMT(log_hdr);
-  if (hx - 0x3FEE0000u < 0x00030900u) {
-    // |x' - 1| small: the polynomial path of __log_fma
-    lg = log_near1(asdouble(((uint64_t)hx << 32) | lo));
-  } else {
-    const double Ln2hi = H[0], Ln2lo = H[1];
-    const double *A = H + 2;
-    const uint32_t th = hx - 0x3FE60000u;
-    const int i2 = (int)((th >> 13) & 127u);
-    const int k2 = (int)th >> 20;
-    const uint32_t izh = hx - (th & 0xFFF00000u);
-    const double z = asdouble(((uint64_t)izh << 32) | lo);
-    const double invc = GMT(log_tab)[2 * i2], logc = GMT(log_tab)[2 * i2 + 1];
-    const double kd = (double)k2;
-    const double r = fma_(z, invc, -1.0);
-    const double w = fma_(kd, Ln2hi, logc);
-    const double t1 = fma_(r, A[2], A[1]);
-    const double hi_ = r + w;
-    const double r2 = r * r;
-    double lo_ = (w - hi_) + r;
-    lo_ = fma_(kd, Ln2lo, lo_);
-    const double r3 = r * r2;
-    const double t2 = fma_(r, A[4], A[3]);
-    const double s_ = fma_(r2, A[0], lo_);
-    const double p_ = fma_(t2, r2, t1);
-    const double q_ = fma_(r3, p_, s_);
-    lg = q_ + hi_;
-  }
+  const double y = (double)a.ky;
   const double zz = y * log10_2lo + ivln10 * lg;
   return zz + y * log10_2hi;
 }
+// log10_norm: the caller guarantees a positive, normal, finite argument (tau_table_position passes
+// max(1e-20, tau)); log10_pos adds the check and falls back to log10_.
+C2R_MHD double log10_norm(double x, const double *tab) {
+  const Log10Arg a = log10_split(x);
+  const double lg = log10_near1(a) ? log_near1(log10_arg_value(a)) : log_table_path(a, tab);
+  return log10_finish(a, lg);
+}
+C2R_MHD const double *log_table() { return GMT(log_tab); }
+C2R_MHD double log10_norm(double x) { return log10_norm(x, GMT(log_tab)); }
 C2R_MHD double log10_pos(double x) {
   const uint32_t hi = (uint32_t)(asuint64(x) >> 32);
   if (hi - 0x00100000u >= 0x7FE00000u) return log10_(x); // zero, subnormal, negative, inf, nan

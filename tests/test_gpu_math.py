@@ -54,6 +54,46 @@ def test_ieee_ops_bit_exact(probe):
         assert np.array_equal(run(probe, 4, x, y), x / y)
 
 
+def test_reciprocal_and_volume_division_bit_exact(probe):
+    """recip_nr (scale_int2/3's 1/x without operand scaling) and div_by_vol (Markstein's sequence with the
+    quotient-magnitude guard) against the IEEE division, inside and outside their fast ranges."""
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    x = 10.0 ** rng.uniform(-150, 150, n)
+    # mantissas of all ones and their neighbours: where the reciprocal's last Newton step is most delicate
+    edge = np.ldexp(np.nextafter(2.0, 0.0), rng.integers(-400, 400, 4096))
+    x[:4096] = edge
+    x[4096:8192] = np.nextafter(edge[:4096], 0.0)
+    x[8192:12288] = np.ldexp(1.0, rng.integers(-400, 400, 4096))
+    assert np.array_equal(run(probe, 5, x), 1.0 / x)
+    a = 10.0 ** rng.uniform(-320, 300, n) * rng.choice([-1.0, 1.0], n)
+    a[:1000] = 0.0
+    b = 10.0 ** rng.uniform(-30, 130, n)       # vol_ph ~ 1e60..1e75; below 1 the guard sends everything to the division
+    b[1000:2000] = 10.0 ** rng.uniform(-300, 300, 1000)
+    with np.errstate(over="ignore", under="ignore"):
+        assert np.array_equal(run(probe, 6, a, b), a / b)
+        assert np.array_equal(run(probe, 7, a, b), (a * 2.0 ** -30) / b)
+        assert np.array_equal(run(probe, 8, a, b), np.zeros(n))
+
+
+def test_pair_table_position_equals_single(probe):
+    """tau_table_positions (both logs as one straight line, polynomial path on demand) == tau_table_position."""
+    rng = np.random.default_rng(8)
+    n = 1_000_000
+    ta = 10.0 ** rng.uniform(-22, 5, n)
+    tb = ta * (1.0 + 10.0 ** rng.uniform(-9, 1, n))
+    ta[:1000] = 0.0
+    ta[1000:2000] = rng.uniform(0.9, 1.1, 1000)
+    one_a, one_b = run(probe, 11, ta), run(probe, 11, tb)
+    assert np.array_equal(run(probe, 9, ta, tb), one_a)
+    assert np.array_equal(run(probe, 10, ta, tb), one_b)
+    # and the single version against glibc's log10 on the host
+    lt = np.array([math.log10(max(1e-20, v)) for v in ta[:200_000]])
+    od = np.minimum(2000.0, 1.0 + (lt + 20.0) / ((4.0 + 20.0) / 2000.0))
+    ip = np.floor(od)
+    assert np.array_equal(one_a[:200_000], ip + (od - ip) * 0.5)
+
+
 def _cases(n):
     rng = np.random.default_rng(2)
     return [("exp", 0, -10.0 ** rng.uniform(-12, 3.2, n), None),
