@@ -428,7 +428,11 @@ C2R_HD TauPos table_position_of_log(double lt) {
   const double odpos = dmin_num((double)NTAU, 1.0 + quo);
   TauPos p;
   p.ipos = (int)odpos;
+#if defined(__HIP_DEVICE_COMPILE__)
+  p.residual = __builtin_amdgcn_fract(odpos); // odpos - floor(odpos), exact; odpos >= 0
+#else
   p.residual = odpos - (double)p.ipos;
+#endif
   return p;
 }
 #if !defined(C2R_USE_PLATFORM_LIBM)

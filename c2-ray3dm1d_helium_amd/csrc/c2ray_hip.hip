@@ -31,29 +31,29 @@ using namespace c2r;
 
 namespace {
 
-constexpr int MAXB = 16;      // sources per batch of launches (kernel-argument array)
+constexpr int BATCH_MAX = 4096; // sources in flight per batch (device-resident records, no kernel-argument limit)
 constexpr int BLOCK = 256;
 
 struct Grid {
   int n1, n2, n3;
   int l1, l2, l3; // left extent mesh/2 (evolve_source.F90:105)
   size_t ncell;
-  size_t colsize; // entries of one shell-ordered column array: (2*smax+1)^3
+  size_t colsize; // entries of one shell-ordered column array that holds the whole mesh: (2*smax+1)^3
   int smax;       // largest L-infinity shell index, max(l1,l2,l3)
 };
 
-struct SrcInfo {
+// One source of the batch in flight, in device memory (read through the scalar cache: uniform per block).
+struct SrcDev {
   int i0, j0, k0;      // 1-based mesh position (srcpos)
-  int lo[3], hi[3];    // current sub-box, as offsets last_l - srcpos, last_r - srcpos
+  int lo[3], hi[3];    // FINAL sub-box as offsets last_l - srcpos, last_r - srcpos (set before the rates launch)
   double nflux;        // NormFlux(ns)
   double nflux_sed[2]; // NormFluxPL(ns), NormFluxQPL(ns) (-DPL / -DQUASARS builds), else 0
-  int slot;            // scratch slot
-  int exact;           // sweep: 1 = photon loss of every boundary cell, 0 = of a 1/16 sample (a lower bound)
+  size_t col;          // first double of this source's column block in the scratch arena
+  size_t cz;           // entries per column array of that block: (2*cap+1)^3, cap = shells the block can hold
 };
-struct BatchArgs {
-  int n;
-  int multi;           // some source of the run has a power-law / quasar SED
-  SrcInfo s[MAXB];
+// the sub-box of the round in flight: the same for every active source of a batch (all are in the same round)
+struct Box {
+  int lo[3], hi[3];
 };
 
 struct StepScalars {
@@ -174,17 +174,24 @@ k_transpose_ij(Grid g, Ptr4 P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The photon loss through the surface of the current sub-box, in full, from the columns the sweep has
-// just stored: same thread <-> cell map, same expression and same block partial sums as k_sweep_shell
-// with S.exact = 1, for all shells [s_lo, s_hi] of the round in ONE launch (blockIdx.x counts the blocks
-// of those shells; block_base is the per-shell prefix).  Used when a sampled loss was not decisive.
+// The photon loss through the surface of the current sub-box (evolve_point.F90:310-315) from the columns the
+// sweep has stored, for all shells [s_lo, s_hi] of the round in ONE launch.  A block takes 256 consecutive cells
+// of one shell (the sweep's own thread <-> cell map); its partial sum goes to partial[source][block number
+// within the round], and k_loss_finish adds the partials in that order: the same bits on every run and for
+// every batch composition.
+// `sample` > 1: only every sample-th block is evaluated (blockIdx.x counts those).  Every term is >= 0, so this
+// is a lower bound: enough to show that the loss of a round that cannot be a source's last for geometric
+// reasons exceeds the threshold of evolve_source.F90:136.  Anything a sample does not decide is redone with
+// sample = 1, and only such full sums are ever kept.
+// (Inside k_sweep_shell this work sat in a sixteenth of the waves, all of them on two of the eight XCDs: the
+// last shell of every round took twice as long as its neighbours.  Here every lane of every wave has a cell.)
 __global__ void __launch_bounds__(BLOCK)
-k_loss_exact(Grid g, BatchArgs ba, int s_lo, int s_hi, StepScalars sc, const double *__restrict__ col,
-             const BandData *__restrict__ bd, SedSet ss, const int *__restrict__ block_base,
-             double *__restrict__ loss_partial, int blocks_total) {
+k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int multi, int s_lo, int s_hi, Box box,
+       StepScalars sc, const double *__restrict__ arena, const BandData *__restrict__ bd, SedSet ss,
+       const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
   __shared__ double sh[BLOCK / 64];
-  const SrcInfo &S = ba.s[blockIdx.y];
-  const int B = block_base[s_lo] + (int)blockIdx.x;
+  const SrcDev &S = src[list[blockIdx.y]];
+  const int B = block_base[s_lo] + (int)blockIdx.x * sample;
   int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -197,14 +204,14 @@ k_loss_exact(Grid g, BatchArgs ba, int s_lo, int s_hi, StepScalars sc, const dou
   if (t < cnt) {
     int di, dj, dk;
     shell_decode(shell, (int)t, di, dj, dk);
-    const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] &&
-                        dk <= S.hi[2];
-    const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
-                          dk == S.hi[2];
+    const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
+                        dk <= box.hi[2];
+    const bool boundary = di == box.lo[0] || dj == box.lo[1] || dk == box.lo[2] || di == box.hi[0] || dj == box.hi[1] ||
+                          dk == box.hi[2];
     if (inside && boundary) {
-      const size_t cz = g.colsize;
+      const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      const double *cs = col + (size_t)S.slot * 6 * cz;
+      const double *cs = arena + S.col;
       const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
       const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
       if (cin_HI < max_coldensh) {
@@ -218,7 +225,7 @@ k_loss_exact(Grid g, BatchArgs ba, int s_lo, int s_hi, StepScalars sc, const dou
           vol_ph = 4.0 * pi * dist2 * path;
         }
         double po;
-        if (ba.multi) {
+        if (multi) {
           const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
           po = photo_out_multi(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, nf);
         } else {
@@ -230,123 +237,103 @@ k_loss_exact(Grid g, BatchArgs ba, int s_lo, int s_hi, StepScalars sc, const dou
     }
   }
   const double bs = block_sum(loss, sh);
-  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * blocks_total + B] = bs;
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + blockIdx.x] = bs;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Column sweep of one shell for every source of the batch (blockIdx.y = source).
-// evolve0D, files_for_3D/evolve_point.F90:114-168 and :237-244, with cinterp
-// (column_density.f90:28-345); boundary photon loss :310-315.
-// col layout: [slot][6][colsize] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII), each array in SHELL ORDER
-// (shell_position of the cell's offset from its source): thread t of shell s owns entry
+// Column sweep of one shell for every active source of the batch (blockIdx.y counts `active`).
+// evolve0D, files_for_3D/evolve_point.F90:114-168 and :237-244, with cinterp (column_density.f90:28-345).
+// A source's column block in the arena: [6][cz] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII), each array in SHELL
+// ORDER (shell_position of the cell's offset from its source): thread t of shell s owns entry
 // shell_offset(s)+t, so all six stores and -- because the corners of consecutive cells are consecutive
 // cells of the previous shell on every face, the i-faces included -- the twelve corner loads are
 // coalesced.  (In mesh order the i-faces of a shell are one cell per 128-byte line.)
 __global__ void __launch_bounds__(BLOCK)
-k_sweep_shell(Grid g, BatchArgs ba, int shell, StepScalars sc, const double *__restrict__ ndens,
-              const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
-              const double *__restrict__ stateT, double *__restrict__ col,
-              const BandData *__restrict__ bd, SedSet ss, double *__restrict__ loss_partial, int blocks_total,
-              int block_base, const float *__restrict__ lls_grid) {
-  __shared__ double sh[BLOCK / 64];
-  const SrcInfo &S = ba.s[blockIdx.y];
+k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ active, int shell, Box box, StepScalars sc,
+              const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
+              const double *__restrict__ stateT, double *__restrict__ arena, const float *__restrict__ lls_grid) {
+  const SrcDev &S = src[active[blockIdx.y]];
   const long long cnt = shell_count(shell);
-  const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
-  double loss = 0.0;
-  if (t < cnt) {
-    int di, dj, dk;
-    shell_decode(shell, (int)t, di, dj, dk);
-    const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] &&
-                        dk <= S.hi[2];
-    if (inside) {
-      const size_t nc = g.ncell, cz = g.colsize;
-      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      double *cs = col + (size_t)S.slot * 6 * cz;
-      double nd, h0, he0, he1;
-      const int w_ = 2 * shell + 1;
-      if (shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
-        // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies
-        const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
-        const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
-        nd = stateT[qT];
-        h0 = dmax(stateT[qT + nc], epsilon);
-        he0 = dmax(stateT[qT + 2 * nc], epsilon);
-        he1 = dmax(stateT[qT + 3 * nc], epsilon);
-      } else {
-        const size_t q = cell_index(g, S.i0, S.j0, S.k0, di, dj, dk);
-        nd = ndens[q];
-        h0 = dmax(xh_av[q], epsilon);
-        he0 = dmax(xhe_av[q], epsilon);
-        he1 = dmax(xhe_av[q + nc], epsilon);
-      }
-      double cin_HI, cin_HeI, cin_HeII, path, vol_ph;
-      if (shell == 0) {
-        cin_HI = cin_HeI = cin_HeII = 0.0;
-        path = 0.5 * sc.dr1;
-        vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
-      } else {
-        ShortChar s4;
-        short_characteristic(S.i0, S.j0, S.k0, di, dj, dk, s4);
-        size_t qc[4];
+  // Which 256 cells of the shell this block takes.  Blocks are dealt round-robin over the 8 XCDs, each with its
+  // own L2: with block b on cells [256 b, 256 b + 256) the two rows of the previous shell that a row of cells
+  // reads are fetched by two or three XCDs.  Instead the blocks of one XCD (equal b mod 8) take one contiguous
+  // eighth of the shell, so that a previous-shell line is fetched by one L2 (the host rounds launches of 64
+  // blocks or more up to a multiple of 8; the surplus blocks leave at once).
+  const int nblk_shell = (int)((cnt + BLOCK - 1) / BLOCK);
+  int vb = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0) {
+    const int chunk = (int)gridDim.x >> 3;
+    vb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  }
+  if (vb >= nblk_shell) return;
+  const long long t = (long long)vb * BLOCK + threadIdx.x;
+  if (t >= cnt) return;
+  int di, dj, dk;
+  shell_decode(shell, (int)t, di, dj, dk);
+  const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
+                      dk <= box.hi[2];
+  if (!inside) return;
+  const size_t nc = g.ncell, cz = S.cz;
+  const size_t p = (size_t)shell_offset(shell) + (size_t)t;
+  double *cs = arena + S.col;
+  double nd, h0, he0, he1;
+  const int w_ = 2 * shell + 1;
+  if (shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
+    // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies
+    const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
+    const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
+    nd = stateT[qT];
+    h0 = dmax(stateT[qT + nc], epsilon);
+    he0 = dmax(stateT[qT + 2 * nc], epsilon);
+    he1 = dmax(stateT[qT + 3 * nc], epsilon);
+  } else {
+    const size_t q = cell_index(g, S.i0, S.j0, S.k0, di, dj, dk);
+    nd = ndens[q];
+    h0 = dmax(xh_av[q], epsilon);
+    he0 = dmax(xhe_av[q], epsilon);
+    he1 = dmax(xhe_av[q + nc], epsilon);
+  }
+  double cin_HI, cin_HeI, cin_HeII, path;
+  if (shell == 0) {
+    cin_HI = cin_HeI = cin_HeII = 0.0;
+    path = 0.5 * sc.dr1;
+  } else {
+    ShortChar s4;
+    short_characteristic(S.i0, S.j0, S.k0, di, dj, dk, s4);
+    size_t qc[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) qc[c] = shell_position(s4.ci[c], s4.cj[c], s4.ck[c]);
-        const double *oH = cs + 3 * cz, *oHe0 = cs + 4 * cz, *oHe1 = cs + 5 * cz;
-        cin_HI = interp_column(s4, oH[qc[0]], oH[qc[1]], oH[qc[2]], oH[qc[3]], sigma_HI_at_ion_freq);
-        cin_HeI = interp_column(s4, oHe0[qc[0]], oHe0[qc[1]], oHe0[qc[2]], oHe0[qc[3]], sigma_HeI_at_ion_freq);
-        cin_HeII = interp_column(s4, oHe1[qc[0]], oHe1[qc[1]], oHe1[qc[2]], oHe1[qc[3]], sigma_HeII_at_ion_freq);
-        path = s4.path * sc.dr1;
-        const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
-        const double dist2 = xs * xs + ys * ys + zs * zs;
-        vol_ph = 4.0 * pi * dist2 * path;
-        if (sc.use_lls) {
-          // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180); the per-cell
-          // grid is LLS_point of type_of_LLS = 2 (REAL(4), mat_ini_cubep3m.F90:859-870)
-          const double coldensh_LLS =
-              lls_grid ? (double)lls_grid[cell_index(g, S.i0, S.j0, S.k0, di, dj, dk)] : sc.coldensh_lls;
-          cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
-        }
-      }
-      const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
-      const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
-      const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
-      cs[p] = cin_HI;
-      cs[p + cz] = cin_HeI;
-      cs[p + 2 * cz] = cin_HeII;
-      cs[p + 3 * cz] = cout_HI;
-      cs[p + 4 * cz] = cout_HeI;
-      cs[p + 5 * cz] = cout_HeII;
-      const bool boundary = di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] ||
-                            dk == S.hi[2];
-      // The loss of a round that is certainly not a source's last only has to show that it exceeds the
-      // threshold of evolve_source.F90:136.  Every term is >= 0, so one wave in 16 of the boundary cells
-      // gives a lower bound (S.exact == 0; whole waves, or the other lanes would idle through the same
-      // code).  Rounds whose loss is kept are evaluated in full (k_loss_exact when the sample was not
-      // decisive).
-      if (boundary && cin_HI < max_coldensh && (S.exact || (((int)t >> 6) & 15) == 0)) {
-        double po;
-        if (ba.multi) {
-          const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-          po = photo_out_multi(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, nf);
-        } else {
-          po = photo_out_only(*bd, ss.photo_thick[0], ss.photo_thin[0], cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII,
-                              cout_HeII, S.nflux);
-        }
-        loss = po * sc.vol / vol_ph;
-      }
+    for (int c = 0; c < 4; c++) qc[c] = shell_position(s4.ci[c], s4.cj[c], s4.ck[c]);
+    const double *oH = cs + 3 * cz, *oHe0 = cs + 4 * cz, *oHe1 = cs + 5 * cz;
+    cin_HI = interp_column(s4, oH[qc[0]], oH[qc[1]], oH[qc[2]], oH[qc[3]], sigma_HI_at_ion_freq);
+    cin_HeI = interp_column(s4, oHe0[qc[0]], oHe0[qc[1]], oHe0[qc[2]], oHe0[qc[3]], sigma_HeI_at_ion_freq);
+    cin_HeII = interp_column(s4, oHe1[qc[0]], oHe1[qc[1]], oHe1[qc[2]], oHe1[qc[3]], sigma_HeII_at_ion_freq);
+    path = s4.path * sc.dr1;
+    if (sc.use_lls) {
+      // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180); the per-cell
+      // grid is LLS_point of type_of_LLS = 2 (REAL(4), mat_ini_cubep3m.F90:859-870)
+      const double coldensh_LLS =
+          lls_grid ? (double)lls_grid[cell_index(g, S.i0, S.j0, S.k0, di, dj, dk)] : sc.coldensh_lls;
+      cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
     }
   }
-  const double bs = block_sum(loss, sh);
-  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * blocks_total + block_base + blockIdx.x] = bs;
+  const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
+  const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
+  const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
+  cs[p] = cin_HI;
+  cs[p + cz] = cin_HeI;
+  cs[p + 2 * cz] = cin_HeII;
+  cs[p + 3 * cz] = cout_HI;
+  cs[p + 4 * cz] = cout_HeI;
+  cs[p + 5 * cz] = cout_HeII;
 }
 
 // photon_loss_src_thread(tn) += ... (evolve_point.F90:312): sum the block partials of all shells of
 // one sub-box round, per source (blockIdx.x).  Fixed shape (256 strided serial sums, then the
 // block tree) => the same bits on every run.
 __global__ void __launch_bounds__(BLOCK)
-k_loss_finish(const double *__restrict__ loss_partial, int blocks_total, int first, int count,
-              double *__restrict__ loss_acc) {
+k_loss_finish(const double *__restrict__ loss_partial, int pitch, int count, double *__restrict__ loss_acc) {
   __shared__ double sh[BLOCK / 64];
-  const double *p = loss_partial + (size_t)blockIdx.x * blocks_total + first;
+  const double *p = loss_partial + (size_t)blockIdx.x * pitch;
   double a = 0.0;
   for (int i = threadIdx.x; i < count; i += BLOCK) a += p[i];
   const double tot = block_sum(a, sh);
@@ -355,7 +342,7 @@ k_loss_finish(const double *__restrict__ loss_partial, int blocks_total, int fir
 
 // columns of one slot from shell order back to mesh order (diagnostic download only)
 __global__ void __launch_bounds__(BLOCK)
-k_col_to_grid(Grid g, SrcInfo S, const double *__restrict__ cs, double *__restrict__ out) {
+k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restrict__ out) {
   const size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (q >= g.ncell) return;
   const int i = (int)(q % g.n1), j = (int)((q / g.n1) % g.n2), k = (int)(q / ((size_t)g.n1 * g.n2));
@@ -363,18 +350,22 @@ k_col_to_grid(Grid g, SrcInfo S, const double *__restrict__ cs, double *__restri
             dk = wrap0(k + 1 - S.k0 + g.l3, g.n3) - g.l3;
   const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] && dk <= S.hi[2];
   const size_t p = shell_position(di, dj, dk);
-  for (int c = 0; c < 3; c++) out[q + c * g.ncell] = inside ? cs[p + (size_t)(3 + c) * g.colsize] : 0.0;
+  for (int c = 0; c < 3; c++) out[q + c * g.ncell] = inside ? cs[p + (size_t)(3 + c) * S.cz] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // Rates of every cell from every source of the batch, accumulated in source order
 // (evolve_point.F90:246-306 with photoion_rates, radiation_photoionrates.f90:108-277).
 // rates layout: [phih | phihe0 | phihe1 | phiheat] each ncell.
+#ifndef C2R_RATES_WAVES_ISO
+#define C2R_RATES_WAVES_ISO 5
+#endif
 template <bool HEAT, bool MULTI>
-__global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? 4 : 4) : (HEAT ? 4 : 5))
-k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, const double *__restrict__ xh_av,
-        const double *__restrict__ xhe_av, const double *__restrict__ col, const BandData *__restrict__ bd,
-        SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles, int tile_base) {
+__global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? 4 : 4) : (HEAT ? 4 : C2R_RATES_WAVES_ISO))
+k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const double *__restrict__ ndens,
+        const double *__restrict__ xh_av, const double *__restrict__ xhe_av, const double *__restrict__ arena,
+        const BandData *__restrict__ bd, SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles,
+        const int *__restrict__ tile_ptr, const int *__restrict__ tile_src, int tile_base) {
   const size_t nc = g.ncell;
   // One block = a tile of 8 x 8 x 4 cells, one wave = a 4 x 4 x 4 cube of it.  Neighbouring cells see
   // similar optical depths: the lanes of a cube mostly take the same branch of the bit-exact log (its
@@ -383,7 +374,10 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
   // consecutive i.  With sub-boxes much smaller than the mesh a cube also keeps ~(w/(w+3))^3 of its lanes
   // busy for a box of width w instead of w/(w+63).  Loads are 16 segments of 32 B; the kernel is ALU-bound.
   // `tiles`, when given, lists the tiles that intersect a sub-box of the batch (built on the host): the
-  // launch then holds only blocks with work, which keeps enough heavy waves resident per SIMD.
+  // launch then holds only blocks with work, which keeps enough heavy waves resident per SIMD.  With it come
+  // `tile_ptr` / `tile_src`: for each listed tile the sources (positions in `src`, ascending = source order)
+  // whose sub-box reaches into it, so that a batch of hundreds of faint sources costs a cell only the sources
+  // near it.  Without lists every cell walks all nsrc sources of the batch (few sources, boxes that fill the mesh).
   // the (invc, logc) table of the bit-exact log (2 KB) in LDS: two gathers per band iteration that no longer
   // queue behind the photo-table gathers in the vector memory path
   __shared__ double s_logtab[256];
@@ -407,8 +401,10 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
   Ricotti ric = {};
   if (HEAT) ric = ricotti_parameters(h1);
   bool touched = false;
-  for (int b = 0; b < ba.n; b++) {
-    const SrcInfo &S = ba.s[b];
+  const int slot = tile_base + (int)blockIdx.x;
+  const int e0 = tile_ptr ? tile_ptr[slot] : 0, e1 = tile_ptr ? tile_ptr[slot + 1] : nsrc;
+  for (int e = e0; e < e1; e++) {
+    const SrcDev &S = src[tile_ptr ? tile_src[e] : e];
     // unwrapped offset rtpos - srcpos in [-mesh/2, mesh - mesh/2 - 1]
     int di = i + 1 - S.i0, dj = j + 1 - S.j0, dk = k + 1 - S.k0;
     di = wrap0(di + g.l1, g.n1) - g.l1;
@@ -419,9 +415,9 @@ k_rates(Grid g, BatchArgs ba, StepScalars sc, const double *__restrict__ ndens, 
     // of the box is traced exactly once, so "inside the box" is the same set and needs no zeroing.)
     if (di < S.lo[0] || di > S.hi[0] || dj < S.lo[1] || dj > S.hi[1] || dk < S.lo[2] || dk > S.hi[2]) continue;
     touched = true;
-    const size_t cz = g.colsize;
+    const size_t cz = S.cz;
     const size_t p = shell_position(di, dj, dk);
-    const double *cs = col + (size_t)S.slot * 6 * cz;
+    const double *cs = arena + S.col;
     const double cout_HI = cs[p + 3 * cz];
     const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
     const double cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
@@ -785,12 +781,26 @@ struct c2r_ctx {
   double *d_rates = nullptr, *d_rates_own = nullptr;
   size_t rates_count = 0;
 
-  int batch = 8;
-  double *d_col = nullptr;
-  size_t col_slots = 0;
+  int batch = 256;                 // most sources per batch (c2r_set_batch); the scratch arena may allow fewer
+  // Column scratch: one arena of two halves (ping-pong sets); a source's block holds the shells it is expected
+  // to need (shell-ordered arrays are prefixes of one another, so a block that turns out too small moves by
+  // six copies).  Zeroed at allocation and only ever holding finite columns afterwards.
+  double *d_arena = nullptr;
+  size_t arena_half = 0;           // doubles per half
+  size_t arena_used[2] = {0, 0};
+  std::vector<int> prev_nbox;      // per source: sub-boxes of the last pass (0: unknown), sizes the next block
+  SrcDev *d_src[2] = {nullptr, nullptr}, *h_src[2] = {nullptr, nullptr}; // source records of the two sets (h: pinned)
+  int *d_list[2] = {nullptr, nullptr}, *h_list[2] = {nullptr, nullptr};  // active lists of a batch's rounds, one after another
+  size_t list_cap = 0;             // ints per set
   double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
-  int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr}; // tile lists of the rates launches (h: pinned)
-  std::vector<unsigned char> tile_mark;
+  size_t loss_partial_cap = 0;     // doubles
+  // rates launches: listed tiles, and for each the sources that reach it (CSR), per set (h: pinned)
+  int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr};
+  int *d_tptr[2] = {nullptr, nullptr}, *h_tptr[2] = {nullptr, nullptr};
+  int *d_tsrc[2] = {nullptr, nullptr}, *h_tsrc[2] = {nullptr, nullptr};
+  size_t tsrc_cap[2] = {0, 0};
+  size_t ntiles = 0;
+  std::vector<int> tile_count;     // scratch of the CSR construction
   int *d_block_base = nullptr;     // device copy of block_base
   int blocks_total = 0;            // blocks of all shells 0..smax
   std::vector<int> block_base;     // first block of shell s in a partial-sum row
@@ -799,10 +809,11 @@ struct c2r_ctx {
   double *d_rc_last = nullptr;     // 12: coefficients left by the last cell of the chemistry pass
   double *d_stat = nullptr;        // STAT_BLOCKS*5 partials + 8 results
   double *h_stat = nullptr;        // pinned, 8
-  double *h_loss = nullptr; // pinned
+  double *h_loss = nullptr; // pinned, BATCH_MAX
   int *d_conv = nullptr;
   int *h_conv = nullptr;    // pinned
-  int last_slot = 0, last_src = 0;
+  int last_src = 0;
+  size_t last_col = 0, last_cz = 0; // column block of the last source swept (c2r_download_columns)
   int last_lo[3] = {0, 0, 0}, last_hi[3] = {0, 0, 0};
 
   double photon_loss[C2R_NFREQ] = {0};
@@ -871,23 +882,50 @@ static hipError_t zero_device(void *ptr, size_t bytes, hipStream_t stream) {
   return hipSuccess;
 }
 
-static int alloc_col(c2r_ctx *c) {
-  if (c->d_col && c->col_slots >= (size_t)c->batch) return 0;
-  if (c->d_col) HIPCHK(c, hipFree(c->d_col));
-  c->d_col = nullptr;
-  c->col_slots = 0;
-  // two ping-pong sets of `batch` slots; on a mesh too large for that (6.5 GB per slot at 512^3, 22 GB at
-  // 768^3) the batch shrinks to what fits in 80 % of the free memory instead of failing
-  const size_t slot = sizeof(double) * 6 * c->g.colsize;
+static size_t block_doubles(int cap) { // doubles of a column block that holds shells 0..cap
+  const size_t w = (size_t)(2 * cap + 1);
+  return 6 * w * w * w;
+}
+
+// The arena holds at least `need_half` doubles per half afterwards (or the call fails).  Growing means a new
+// allocation: nothing may be in flight, and the columns of both sets are lost (callers restart their batch).
+static int ensure_arena(c2r_ctx *c, size_t need_half, bool *grown) {
+  if (grown) *grown = false;
+  if (c->d_arena && c->arena_half >= need_half) return 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream2));
+  if (c->d_arena) HIPCHK(c, hipFree(c->d_arena));
+  c->d_arena = nullptr;
+  c->arena_half = 0;
   size_t free_b = 0, total_b = 0;
   HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-  const size_t fit = (size_t)(0.8 * (double)free_b) / (2 * slot);
-  if (fit < 1) return fail(c, "column scratch: one slot of %.1f GB x 2 does not fit in %.1f GB of free device memory", slot / 1e9, free_b / 1e9);
-  if ((size_t)c->batch > fit) c->batch = (int)fit;
-  HIPCHK(c, hipMalloc(&c->d_col, slot * c->batch * 2));
-  HIPCHK(c, zero_device(c->d_col, slot * c->batch * 2, c->stream));
+  const size_t limit = (size_t)(0.8 * (double)free_b) / (2 * sizeof(double));
+  if (need_half > limit)
+    return fail(c, "column scratch: two halves of %.1f GB do not fit in %.1f GB of free device memory", need_half * 8e-9,
+                free_b / 1e9);
+  // some room to grow into, so that the next larger batch does not reallocate again
+  size_t want = std::min(limit, std::max(need_half + need_half / 2, (size_t)1 << 27));
+  HIPCHK(c, hipMalloc(&c->d_arena, sizeof(double) * 2 * want));
+  HIPCHK(c, zero_device(c->d_arena, sizeof(double) * 2 * want, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->col_slots = c->batch;
+  c->arena_half = want;
+  c->arena_used[0] = c->arena_used[1] = 0;
+  c->set_busy[0] = c->set_busy[1] = false;
+  if (grown) *grown = true;
+  return 0;
+}
+
+template <class T>
+static int ensure_pair(c2r_ctx *c, T **d, T **h, size_t *cap, size_t need) {
+  if (*cap >= need) return 0;
+  if (*d) HIPCHK(c, hipFree(*d));
+  if (h && *h) HIPCHK(c, hipHostFree(*h));
+  *d = nullptr;
+  if (h) *h = nullptr;
+  const size_t want = need + need / 2 + 1024;
+  HIPCHK(c, hipMalloc(d, sizeof(T) * want));
+  if (h) HIPCHK(c, hipHostMalloc(h, sizeof(T) * want));
+  *cap = want;
   return 0;
 }
 
@@ -955,18 +993,23 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   for (int s = 0; s <= c->g.smax; s++)
     c->block_base[s + 1] = c->block_base[s] + (int)((shell_count(s) + BLOCK - 1) / BLOCK);
   c->blocks_total = c->block_base[c->g.smax + 1];
-  CR(hipMalloc(&c->d_loss_partial, sizeof(double) * (size_t)c->blocks_total * MAXB));
   CR(hipMalloc(&c->d_block_base, sizeof(int) * c->block_base.size()));
   CR(hipMemcpy(c->d_block_base, c->block_base.data(), sizeof(int) * c->block_base.size(), hipMemcpyHostToDevice));
-  {
-    const size_t ntiles = (size_t)((mesh[0] + 7) / 8) * ((mesh[1] + 7) / 8) * ((mesh[2] + 3) / 4);
-    for (int k = 0; k < 2; k++) {
-      CR(hipMalloc(&c->d_tiles[k], sizeof(int) * ntiles));
-      CR(hipHostMalloc(&c->h_tiles[k], sizeof(int) * ntiles));
-    }
+  c->ntiles = (size_t)((mesh[0] + 7) / 8) * ((mesh[1] + 7) / 8) * ((mesh[2] + 3) / 4);
+  for (int k = 0; k < 2; k++) {
+    CR(hipMalloc(&c->d_tiles[k], sizeof(int) * c->ntiles));
+    CR(hipHostMalloc(&c->h_tiles[k], sizeof(int) * c->ntiles));
+    CR(hipMalloc(&c->d_tptr[k], sizeof(int) * (c->ntiles + 1)));
+    CR(hipHostMalloc(&c->h_tptr[k], sizeof(int) * (c->ntiles + 1)));
+    CR(hipMalloc(&c->d_src[k], sizeof(SrcDev) * BATCH_MAX));
+    CR(hipHostMalloc(&c->h_src[k], sizeof(SrcDev) * BATCH_MAX));
+    // active lists of all rounds of a batch, one after another (two per round at most, plus the final losses)
+    c->list_cap = (size_t)(2 * (c->g.smax / SUBBOXSIZE + 2) + 4) * BATCH_MAX;
+    CR(hipMalloc(&c->d_list[k], sizeof(int) * c->list_cap));
+    CR(hipHostMalloc(&c->h_list[k], sizeof(int) * c->list_cap));
   }
-  CR(hipMalloc(&c->d_loss_acc, sizeof(double) * MAXB));
-  CR(hipHostMalloc(&c->h_loss, sizeof(double) * MAXB));
+  CR(hipMalloc(&c->d_loss_acc, sizeof(double) * BATCH_MAX));
+  CR(hipHostMalloc(&c->h_loss, sizeof(double) * BATCH_MAX));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
   CR(hipHostMalloc(&c->h_conv, sizeof(int)));
   CR(hipMalloc(&c->d_bands, sizeof(BandData)));
@@ -985,13 +1028,17 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_stateT, c->d_col, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl};
+                  c->d_rates_own, c->d_stateT, c->d_arena, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   for (int k = 0; k < 2; k++) {
-    if (c->d_tiles[k]) (void)hipFree(c->d_tiles[k]);
-    if (c->h_tiles[k]) (void)hipHostFree(c->h_tiles[k]);
+    void *dev[] = {c->d_tiles[k], c->d_tptr[k], c->d_tsrc[k], c->d_src[k], c->d_list[k]};
+    void *host[] = {c->h_tiles[k], c->h_tptr[k], c->h_tsrc[k], c->h_src[k], c->h_list[k]};
+    for (void *q : dev)
+      if (q) (void)hipFree(q);
+    for (void *q : host)
+      if (q) (void)hipHostFree(q);
   }
   if (c->h_conv) (void)hipHostFree(c->h_conv);
   if (c->h_stat) (void)hipHostFree(c->h_stat);
@@ -1034,6 +1081,21 @@ extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const doubl
   if ((photo_thick == nullptr) != (photo_thin == nullptr) || (heat_thick == nullptr) != (heat_thin == nullptr))
     return fail(c, "c2r_set_tables: thick and thin tables come in pairs");
   if (bb_upper < 1 || bb_upper > NFREQ) return fail(c, "c2r_set_tables: bb_upper %d not in [1,%d]", bb_upper, NFREQ);
+  // The band loop of the rates kernels leaves out the terms of species that cannot absorb in a band and takes
+  // the reciprocals of scale_int2/3 without operand scaling: both rest on the band layout of
+  // radiation_sizes.f90:375-545 (sigma_HeI = 0 below the He I threshold, sigma_HeII = 0 below the He II
+  // threshold, every other cross section an ordinary number), checked here once.
+  for (int b = 0; b < NFREQ; b++) {
+    const double lo = 0x1p-100, hi = 0x1p-30;
+    const bool he1 = b >= NB1, he2 = b >= NB1 + NB2;
+    const bool ok = sigma_HI[b] >= lo && sigma_HI[b] <= hi &&
+                    (he1 ? (sigma_HeI[b] >= lo && sigma_HeI[b] <= hi) : sigma_HeI[b] == 0.0) &&
+                    (he2 ? (sigma_HeII[b] >= lo && sigma_HeII[b] <= hi) : sigma_HeII[b] == 0.0);
+    if (!ok)
+      return fail(c, "c2r_set_tables: band %d has cross sections (%g, %g, %g): not the band layout of radiation_sizes.f90 "
+                  "(He I / He II cross sections exactly 0 below their thresholds, all others within [2^-100, 2^-30])",
+                  b + 1, sigma_HI[b], sigma_HeI[b], sigma_HeII[b]);
+  }
   HIPCHK(c, hipSetDevice(c->device));
   // without tables this call only sets the band vectors; c2r_build_tables makes the tables on the device
   c->have_tables = false;
@@ -1109,6 +1171,7 @@ extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const do
       return fail(c, "c2r_set_sources: source %d at (%d,%d,%d) outside the mesh", s + 1, p[0], p[1], p[2]);
   }
   c->nsrc = nsrc;
+  c->prev_nbox.assign((size_t)nsrc, 0);
   c->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
   c->normflux.assign(normflux, normflux + nsrc);
   c->s_star = s_star;
@@ -1388,7 +1451,7 @@ extern "C" int c2r_set_rates_to_zero(c2r_ctx *c) {
 
 extern "C" int c2r_set_batch(c2r_ctx *c, int nbatch) {
   if (!c) return 1;
-  if (nbatch < 1 || nbatch > MAXB) return fail(c, "c2r_set_batch: %d not in [1,%d]", nbatch, MAXB);
+  if (nbatch < 1 || nbatch > BATCH_MAX) return fail(c, "c2r_set_batch: %d not in [1,%d]", nbatch, BATCH_MAX);
   c->batch = nbatch;
   return 0;
 }
@@ -1396,20 +1459,48 @@ extern "C" int c2r_set_batch(c2r_ctx *c, int nbatch) {
 // host-side sub-box bookkeeping of one source (do_source, evolve_source.F90:96-144, 233-236)
 struct SrcRun {
   int ns;                 // 1-based source number
-  int lastpos_r[3], lastpos_l[3]; // as offsets from srcpos
-  int last_r[3], last_l[3];       // current box, offsets
   int nbox = 0;
   double total_flux = 0, loss = 0;
   bool active = true;
-  bool exact = true;      // this round's photon loss is kept (last round for geometric reasons): evaluate it in full
+  bool final_loss_due = false; // the last round ended for geometric reasons: its full loss is evaluated after the sweep
+  int cap = 0;            // shells the column block can hold
   int smax_prev = -1;     // largest shell already swept
 };
 
-static int box_smax(const SrcRun &r) {
+// extent of the mesh as seen from a source, periodic_bc = .true. (evolve_source.F90:103-105)
+struct Reach {
+  int l[3], r[3];
+};
+static Reach mesh_reach(const Grid &g) {
+  const int mesh[3] = {g.n1, g.n2, g.n3};
+  Reach R;
+  for (int d = 0; d < 3; d++) {
+    R.r[d] = std::min(MAX_SUBBOX, mesh[d] / 2 - 1 + mesh[d] % 2);
+    R.l[d] = -std::min(MAX_SUBBOX, mesh[d] / 2);
+  }
+  return R;
+}
+// the sub-box after `nbox` rounds (evolve_source.F90:141-144)
+static Box round_box(const Reach &R, int nbox) {
+  Box b;
+  for (int d = 0; d < 3; d++) {
+    b.hi[d] = std::min(SUBBOXSIZE * nbox, R.r[d]);
+    b.lo[d] = std::max(-SUBBOXSIZE * nbox, R.l[d]);
+  }
+  return b;
+}
+static int box_smax(const Box &b) {
   int m = 0;
-  for (int d = 0; d < 3; d++) m = std::max(m, std::max(r.last_r[d], -r.last_l[d]));
+  for (int d = 0; d < 3; d++) m = std::max(m, std::max(b.hi[d], -b.lo[d]));
   return m;
 }
+static long long box_cells(const Box &b) {
+  long long v = 1;
+  for (int d = 0; d < 3; d++) v *= (b.hi[d] - b.lo[d] + 1);
+  return v;
+}
+// the while-test of evolve_source.F90:136-139 can still pass after this box (z extent short of the mesh)
+static bool box_can_grow(const Reach &R, const Box &b) { return b.hi[2] < R.r[2] && b.lo[2] > R.l[2]; }
 
 static int pool_event(c2r_ctx *c, hipEvent_t *out) {
   if (c->ev_used == c->ev_pool.size()) {
@@ -1421,7 +1512,31 @@ static int pool_event(c2r_ctx *c, hipEvent_t *out) {
   return 0;
 }
 
-// do_source (evolve_source.F90:66-238) for every source number in `mine`, `batch` at a time.
+constexpr int LOSS_SAMPLE = 16; // a sampled boundary loss evaluates every 16th block of the round's shells
+
+// Photon loss of the round's box for the sources h_list[set][list_off .. +n) (positions in the batch), full
+// (sample = 1) or sampled, into c->h_loss[0..n).  Synchronises the sweep stream.
+static int boundary_loss(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, int s_hi, const Box &box, int sample,
+                         const StepScalars &sc, const SedSet &ss, bool multi) {
+  const int count = c->block_base[s_hi + 1] - c->block_base[s_lo];
+  const int nblk = (count + sample - 1) / sample;
+  const size_t need = (size_t)nblk * n;
+  if (c->loss_partial_cap < need) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ensure_pair<double>(c, &c->d_loss_partial, (double **)nullptr, &c->loss_partial_cap, need)) return 1;
+  }
+  hipLaunchKernelGGL(k_loss, dim3(nblk, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
+                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_arena, c->d_bands, ss, c->d_block_base, c->d_loss_partial, nblk,
+                     sample);
+  hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, nblk, nblk, c->d_loss_acc);
+  c->tm.sweep_launches += 2;
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// do_source (evolve_source.F90:66-238) for every source number in `mine`, up to c->batch at a time.
 // Per batch: the column sweep (dependent shell launches, host test of the sub-box loop) on the
 // high-priority stream, then ONE rates launch for the whole batch on the second stream; the next
 // batch's sweep overlaps it (scratch sets ping-pong).  Rates launches are ordered on their stream,
@@ -1434,17 +1549,18 @@ static int pass_finish(c2r_ctx *c);
 static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   HIPCHK(c, hipSetDevice(c->device));
   if (c->pass_open) return fail(c, "previous c2r_pass_sources_begin was not closed by c2r_pass_sources_end");
-  if (alloc_col(c)) return 1;
   const Grid g = c->g;
   const size_t nc = g.ncell;
   const StepScalars sc = scalars(c);
   bool multi = false;
   const SedSet ss = sedset(c, &multi);
   const int mesh[3] = {g.n1, g.n2, g.n3};
+  const Reach reach = mesh_reach(g);
   c->tm.sweep_ms = c->tm.rates_ms = 0.0;
   c->tm.sweep_launches = c->tm.rates_launches = 0;
   c->tm.cells_swept = 0;
   c->ev_used = 0;
+  if (c->prev_nbox.size() != (size_t)c->nsrc) c->prev_nbox.assign((size_t)c->nsrc, 0);
   std::vector<hipEvent_t> tev; // per batch: sweep start, sweep end, rates start, rates end
   // everything queued earlier on the main stream (state upload, zeroing of the rates) must be
   // visible to the rates stream
@@ -1469,214 +1585,274 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ev_slab.push_back(e);
   }
+  // column blocks: what a source needed in the last pass plus one round, or four rounds when nothing is known;
+  // never less than one round, never more than the mesh
+  auto predicted_cap = [&](int ns) {
+    const int prev = c->prev_nbox[(size_t)ns - 1];
+    return std::min(g.smax, SUBBOXSIZE * (prev > 0 ? prev + 1 : 4));
+  };
   int bi = 0;
-  for (size_t b0 = 0; b0 < mine.size(); b0 += c->batch, bi++) {
-    const int nb = (int)std::min<size_t>(c->batch, mine.size() - b0);
+  int batch_limit = std::min(c->batch, BATCH_MAX);
+  for (size_t b0 = 0; b0 < mine.size(); bi++) {
+    int nb = (int)std::min<size_t>((size_t)batch_limit, mine.size() - b0);
     const int set = bi & 1;
-    const int slot0 = set * c->batch;
-    std::vector<SrcRun> run(nb);
-    for (int b = 0; b < nb; b++) {
-      SrcRun &r = run[b];
-      r.ns = mine[b0 + b];
-      for (int d = 0; d < 3; d++) { // periodic_bc = .true. (evolve_source.F90:103-105)
-        r.lastpos_r[d] = std::min(MAX_SUBBOX, mesh[d] / 2 - 1 + mesh[d] % 2);
-        r.lastpos_l[d] = -std::min(MAX_SUBBOX, mesh[d] / 2);
-        r.last_r[d] = r.last_l[d] = 0;
+    // this set's scratch may still be read by the rates launch of two batches ago, and its pinned lists may
+    // still feed copies queued then
+    if (c->set_busy[set]) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[set], 0));
+      HIPCHK(c, hipEventSynchronize(c->ev_rates_done[set]));
+    }
+    std::vector<SrcRun> run;
+    bool full_caps = false; // after the arena ran out mid-sweep: blocks for the whole mesh, fewer sources
+  restart_batch:
+    run.assign((size_t)nb, SrcRun());
+    {
+      // blocks of this batch; when they do not fit, the arena grows (up to 80 % of the free memory), and when
+      // that is not enough the batch shrinks
+      for (;;) {
+        size_t need = 0;
+        for (int b = 0; b < nb; b++) {
+          run[b].ns = mine[b0 + b];
+          run[b].cap = full_caps ? g.smax : predicted_cap(run[b].ns);
+          need += block_doubles(run[b].cap);
+        }
+        // room for one source to move into a block for the whole mesh without a restart
+        if (!full_caps) need += block_doubles(g.smax);
+        if (need <= c->arena_half) break;
+        const std::string saved = c->err; // a failed growth is not an error yet: the batch shrinks first
+        if (ensure_arena(c, need, nullptr) == 0) break;
+        c->err = saved;
+        if (nb == 1 && full_caps) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
+        if (nb > 1) nb = (nb + 1) / 2; else full_caps = true;
+        run.resize((size_t)nb);
       }
-      r.total_flux = c->normflux[r.ns - 1] * c->s_star; // evolve_source.F90:122-128
-      for (int k = 0; k < 2; k++)
-        if (multi && !c->normflux_sed[k].empty())
-          r.total_flux = r.total_flux + c->normflux_sed[k][r.ns - 1] * c->s_star_sed[k];
-      r.loss = r.total_flux;
+      c->arena_used[set] = 0;
+      SrcDev *hs = c->h_src[set];
+      for (int b = 0; b < nb; b++) {
+        SrcRun &r = run[b];
+        r.total_flux = c->normflux[r.ns - 1] * c->s_star; // evolve_source.F90:122-128
+        for (int k = 0; k < 2; k++)
+          if (multi && !c->normflux_sed[k].empty())
+            r.total_flux = r.total_flux + c->normflux_sed[k][r.ns - 1] * c->s_star_sed[k];
+        r.loss = r.total_flux;
+        SrcDev &S = hs[b];
+        const int *p = &c->srcpos[3 * (size_t)(r.ns - 1)];
+        S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
+        for (int d = 0; d < 3; d++) { S.lo[d] = 0; S.hi[d] = 0; }
+        S.nflux = c->normflux[r.ns - 1];
+        for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][r.ns - 1];
+        S.col = (size_t)set * c->arena_half + c->arena_used[set];
+        const size_t w = (size_t)(2 * r.cap + 1);
+        S.cz = w * w * w;
+        c->arena_used[set] += 6 * S.cz;
+      }
+      HIPCHK(c, hipMemcpyAsync(c->d_src[set], hs, sizeof(SrcDev) * nb, hipMemcpyHostToDevice, c->stream));
     }
     // coldensh_out = 0 for every new source (evolve_source.F90:94-95) serves two purposes in the
     // reference: the "already done" marker (replaced here by the shell order: every cell is visited
-    // once) and finite values for corners whose interpolation weight is exactly 0.  The scratch is
+    // once) and finite values for corners whose interpolation weight is exactly 0.  The arena is
     // zeroed once at allocation and only ever holds finite columns afterwards, so 0*w stays 0.
-
-    // this scratch set may still be read by the rates launch of two batches ago
-    if (c->set_busy[set]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[set], 0));
     hipEvent_t e_s0 = nullptr, e_s1 = nullptr, e_r0 = nullptr, e_r1 = nullptr;
     if (c->timing) {
       if (pool_event(c, &e_s0) || pool_event(c, &e_s1) || pool_event(c, &e_r0) || pool_event(c, &e_r1)) return 1;
       HIPCHK(c, hipEventRecord(e_s0, c->stream));
     }
-    for (;;) {
-      // while-test of evolve_source.F90:136-139 per source
-      BatchArgs ba;
-      ba.n = 0;
-      ba.multi = multi ? 1 : 0;
-      int act_idx[MAXB];
-      int s_lo = 1 << 30, s_hi = -1;
+    size_t list_used = 0;
+    long long batch_cells = 0;
+    int *hl = c->h_list[set];
+    std::vector<int> undecided;
+    for (int round = 1;; round++) {
+      // while-test of evolve_source.F90:136-139 per source; all sources that pass are in round `round`
+      const Box box = round_box(reach, round);
+      const int s_hi = box_smax(box);
+      int nact = 0;
+      int *act = hl + list_used;
+      int s_lo = 1 << 30;
       for (int b = 0; b < nb; b++) {
         SrcRun &r = run[b];
         if (!r.active) continue;
-        if (!(r.loss > C2R_F(1e-10) * r.total_flux && r.last_r[2] < r.lastpos_r[2] && r.last_l[2] > r.lastpos_l[2])) {
+        const Box cur = round_box(reach, r.nbox);
+        if (!(r.loss > C2R_F(1e-10) * r.total_flux && box_can_grow(reach, cur))) {
           r.active = false;
           continue;
         }
         r.nbox++;
         r.loss = 0.0;
-        for (int d = 0; d < 3; d++) {
-          r.last_r[d] = std::min(SUBBOXSIZE * r.nbox, r.lastpos_r[d]);
-          r.last_l[d] = std::max(-SUBBOXSIZE * r.nbox, r.lastpos_l[d]);
-        }
-        // the while-test after this round fails whatever the loss when the box has reached the mesh in z
-        r.exact = !(r.last_r[2] < r.lastpos_r[2] && r.last_l[2] > r.lastpos_l[2]);
-        SrcInfo &S = ba.s[ba.n];
-        const int *p = &c->srcpos[3 * (size_t)(r.ns - 1)];
-        S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
-        for (int d = 0; d < 3; d++) { S.lo[d] = r.last_l[d]; S.hi[d] = r.last_r[d]; }
-        S.nflux = c->normflux[r.ns - 1];
-        for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][r.ns - 1];
-        S.slot = slot0 + b;
-        S.exact = r.exact ? 1 : 0;
-        act_idx[ba.n] = b;
-        ba.n++;
+        act[nact++] = b;
         s_lo = std::min(s_lo, r.smax_prev + 1);
-        s_hi = std::max(s_hi, box_smax(r));
       }
-      if (ba.n == 0) break;
+      if (nact == 0) break;
       if (s_hi > g.smax) return fail(c, "internal: shell %d beyond smax %d", s_hi, g.smax);
-      // All active sources of a batch are in the same sub-box round (a source that stopped early
-      // simply is not in `ba`), so their new shells are s_prev+1 .. smax of the new box.
+      // blocks too small for this round move to larger ones (the shells stored so far are a prefix of every array)
+      for (int a = 0; a < nact; a++) {
+        SrcRun &r = run[act[a]];
+        if (r.cap >= s_hi) continue;
+        const int ncap = std::min(g.smax, std::max(s_hi, 2 * r.cap));
+        const size_t nd = block_doubles(ncap);
+        if (c->arena_used[set] + nd > c->arena_half) {
+          // out of room in the middle of a sweep: nothing of this batch has reached the rate grids yet, so the
+          // batch starts over with blocks for the whole mesh (and fewer sources if need be)
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          full_caps = true;
+          goto restart_batch;
+        }
+        SrcDev &S = c->h_src[set][act[a]];
+        const size_t ncol = (size_t)set * c->arena_half + c->arena_used[set];
+        const size_t wn = (size_t)(2 * ncap + 1), ncz = wn * wn * wn;
+        const size_t wp = (size_t)(2 * r.smax_prev + 1), have = r.smax_prev >= 0 ? wp * wp * wp : 0;
+        for (int k = 0; k < 6 && have > 0; k++)
+          HIPCHK(c, hipMemcpyAsync(c->d_arena + ncol + (size_t)k * ncz, c->d_arena + S.col + (size_t)k * S.cz, sizeof(double) * have,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        S.col = ncol;
+        S.cz = ncz;
+        c->arena_used[set] += nd;
+        r.cap = ncap;
+        HIPCHK(c, hipMemcpyAsync(c->d_src[set] + act[a], &S, sizeof(SrcDev), hipMemcpyHostToDevice, c->stream));
+      }
+      HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, act, sizeof(int) * nact, hipMemcpyHostToDevice, c->stream));
       for (int s = s_lo; s <= s_hi; s++) {
         const int nblk = c->block_base[s + 1] - c->block_base[s];
-        hipLaunchKernelGGL(k_sweep_shell, dim3(nblk, ba.n), dim3(BLOCK), 0, c->stream, g, ba, s, sc, c->d_ndens,
-                           c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_col, c->d_bands, ss, c->d_loss_partial,
-                           c->blocks_total, c->block_base[s], c->lls_on_grid ? c->d_lls : nullptr);
+        // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
+        const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
+        hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + list_used,
+                           s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_arena,
+                           c->lls_on_grid ? c->d_lls : nullptr);
         c->tm.sweep_launches++;
       }
-      hipLaunchKernelGGL(k_loss_finish, dim3(ba.n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, c->blocks_total,
-                         c->block_base[s_lo], c->block_base[s_hi + 1] - c->block_base[s_lo], c->d_loss_acc);
-      c->tm.sweep_launches++;
       HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * MAXB, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      // A sampled loss (a lower bound) that clears the threshold with a factor 2 to spare decides
-      // "continue" and is never looked at again; anything else is replaced by the full sum.
+      const size_t act_off = list_used;
+      list_used += (size_t)nact;
       {
-        BatchArgs bx;
-        bx.n = 0;
-        bx.multi = ba.multi;
-        int redo[MAXB];
-        for (int a = 0; a < ba.n; a++) {
-          SrcRun &r = run[act_idx[a]];
-          r.loss = c->h_loss[a];
-          if (!r.exact && !(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) {
-            bx.s[bx.n] = ba.s[a];
-            bx.s[bx.n].exact = 1;
-            redo[bx.n++] = a;
-          }
-        }
-        if (bx.n > 0) {
-          const int first = c->block_base[s_lo], count = c->block_base[s_hi + 1] - first;
-          hipLaunchKernelGGL(k_loss_exact, dim3(count, bx.n), dim3(BLOCK), 0, c->stream, g, bx, s_lo, s_hi, sc, c->d_col,
-                             c->d_bands, ss, c->d_block_base, c->d_loss_partial, c->blocks_total);
-          hipLaunchKernelGGL(k_loss_finish, dim3(bx.n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, c->blocks_total, first,
-                             count, c->d_loss_acc);
-          c->tm.sweep_launches += 2;
-          HIPCHK(c, hipGetLastError());
-          HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss_acc, sizeof(double) * MAXB, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
-          for (int j = 0; j < bx.n; j++) run[act_idx[redo[j]]].loss = c->h_loss[j];
-        }
+        long long cells = box_cells(box) - (round > 1 ? box_cells(round_box(reach, round - 1)) : 0);
+        batch_cells += cells * nact;
       }
-      for (int a = 0; a < ba.n; a++) {
-        SrcRun &r = run[act_idx[a]];
-        // cells traced in this round: the part of the new box not in the previous one
-        long long vol_new = 1, vol_old = 1;
-        for (int d = 0; d < 3; d++) {
-          vol_new *= (r.last_r[d] - r.last_l[d] + 1);
-          const int pr = std::min(SUBBOXSIZE * (r.nbox - 1), r.lastpos_r[d]);
-          const int pl = std::max(-SUBBOXSIZE * (r.nbox - 1), r.lastpos_l[d]);
-          vol_old *= (pr - pl + 1);
+      for (int a = 0; a < nact; a++) run[act[a]].smax_prev = s_hi;
+      if (!box_can_grow(reach, box)) {
+        // The while-test after this round fails whatever the loss: the round is every active source's last, and
+        // its loss (the one that is kept, evolve_source.F90:233) is evaluated after the sweep, beside the rates.
+        for (int a = 0; a < nact; a++) {
+          run[act[a]].final_loss_due = true;
+          run[act[a]].active = false;
         }
-        c->tm.cells_swept += r.nbox == 1 ? vol_new : vol_new - vol_old;
-        r.smax_prev = box_smax(r);
+        break;
+      }
+      // The loss of this round decides whether the source goes on.  A sampled loss (a lower bound) that clears
+      // the threshold with a factor 2 to spare decides "continue" and is never looked at again; anything else is
+      // replaced by the full sum.
+      if (boundary_loss(c, set, act_off, nact, s_lo, s_hi, box, LOSS_SAMPLE, sc, ss, multi)) return 1;
+      undecided.clear();
+      for (int a = 0; a < nact; a++) {
+        SrcRun &r = run[act[a]];
+        r.loss = c->h_loss[a];
+        if (!(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) undecided.push_back(act[a]);
+      }
+      if (!undecided.empty()) {
+        int *ul = hl + list_used;
+        std::copy(undecided.begin(), undecided.end(), ul);
+        HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, ul, sizeof(int) * undecided.size(), hipMemcpyHostToDevice, c->stream));
+        if (boundary_loss(c, set, list_used, (int)undecided.size(), s_lo, s_hi, box, 1, sc, ss, multi)) return 1;
+        list_used += undecided.size();
+        for (size_t j = 0; j < undecided.size(); j++) run[undecided[j]].loss = c->h_loss[j];
       }
     }
+    // final sub-boxes for the rates launch
+    for (int b = 0; b < nb; b++) {
+      SrcDev &S = c->h_src[set][b];
+      const Box fb = round_box(reach, run[b].nbox);
+      for (int d = 0; d < 3; d++) { S.lo[d] = fb.lo[d]; S.hi[d] = fb.hi[d]; }
+      // a source whose while-test failed before the first sub-box (a mesh only two cells deep) traced nothing:
+      // an empty box, so that no cell passes the in-box test
+      if (run[b].nbox == 0) { S.lo[0] = 1; S.hi[0] = 0; }
+      c->prev_nbox[(size_t)run[b].ns - 1] = run[b].nbox;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_src[set], c->h_src[set], sizeof(SrcDev) * nb, hipMemcpyHostToDevice, c->stream));
     if (c->timing) HIPCHK(c, hipEventRecord(e_s1, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_sweep_done[set], c->stream));
 
     // rates of the whole batch, in source order, on the second stream
-    BatchArgs ba;
-    ba.n = nb;
-    ba.multi = multi ? 1 : 0;
-    for (int b = 0; b < nb; b++) {
-      SrcInfo &S = ba.s[b];
-      const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
-      S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
-      for (int d = 0; d < 3; d++) { S.lo[d] = run[b].last_l[d]; S.hi[d] = run[b].last_r[d]; }
-      // a source whose while-test failed before the first sub-box (a mesh only two cells deep) traced nothing:
-      // an empty box, so that no cell passes the in-box test
-      if (run[b].nbox == 0) { S.lo[0] = 1; S.hi[0] = 0; }
-      S.nflux = c->normflux[run[b].ns - 1];
-      for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][run[b].ns - 1];
-      S.slot = slot0 + b;
-      S.exact = 1;
-    }
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[set], 0));
     if (c->timing) HIPCHK(c, hipEventRecord(e_r0, c->stream2));
-    // tiles (8 x 8 x 4 cells) that intersect the final sub-box of some source of the batch
+    // tiles (8 x 8 x 4 cells) that intersect the final sub-box of some source of the batch, and per tile the
+    // sources that do
     const int nt1 = (g.n1 + 7) / 8, nt2 = (g.n2 + 7) / 8, nt3 = (g.n3 + 3) / 4;
     int nblk = nt1 * nt2 * nt3;
-    const int *d_tiles = nullptr;
+    const int *d_tiles = nullptr, *d_tptr = nullptr, *d_tsrc = nullptr;
     {
       bool full = false;
       for (int b = 0; b < nb && !full; b++) {
-        full = true;
-        for (int d = 0; d < 3; d++) full = full && (run[b].last_r[d] - run[b].last_l[d] + 1 >= mesh[d]);
+        const Box fb = round_box(reach, run[b].nbox);
+        full = run[b].nbox > 0;
+        for (int d = 0; d < 3; d++) full = full && (fb.hi[d] - fb.lo[d] + 1 >= mesh[d]);
       }
-      if (!full) {
-        // the pinned list of this set may still feed the copy queued two batches ago
-        if (c->set_busy[set]) HIPCHK(c, hipEventSynchronize(c->ev_rates_done[set]));
-        std::vector<unsigned char> &mark = c->tile_mark;
-        mark.assign((size_t)nblk, 0);
-        std::vector<unsigned char> cov[3];
+      // few sources one of which fills the mesh: every cell simply walks all of them
+      if (!(full && nb <= 16)) {
+        std::vector<int> &cnt = c->tile_count;
+        cnt.assign((size_t)nblk, 0);
+        std::vector<int> cov[3];
         const int tsz[3] = {8, 8, 4}, ntd[3] = {nt1, nt2, nt3};
-        for (int b = 0; b < nb; b++) {
-          if (run[b].nbox == 0) continue;
+        auto covered = [&](int b) {
+          const Box fb = round_box(reach, run[b].nbox);
           const int *p = &c->srcpos[3 * (size_t)(run[b].ns - 1)];
           for (int d = 0; d < 3; d++) {
-            cov[d].assign((size_t)ntd[d], 0);
-            for (int o = run[b].last_l[d]; o <= run[b].last_r[d]; o++) {
+            cov[d].clear();
+            int last = -1;
+            std::vector<unsigned char> seen((size_t)ntd[d], 0);
+            for (int o = fb.lo[d]; o <= fb.hi[d]; o++) {
               int x = (p[d] - 1 + o) % mesh[d];
               if (x < 0) x += mesh[d];
-              cov[d][x / tsz[d]] = 1;
+              const int t = x / tsz[d];
+              if (t != last && !seen[t]) { seen[t] = 1; cov[d].push_back(t); }
+              last = t;
             }
           }
-          for (int tk = 0; tk < nt3; tk++) {
-            if (!cov[2][tk]) continue;
-            for (int tj_ = 0; tj_ < nt2; tj_++) {
-              if (!cov[1][tj_]) continue;
-              unsigned char *row = &mark[((size_t)tk * nt2 + tj_) * nt1];
-              int ti_ = 0;
-              for (; ti_ + 8 <= nt1; ti_ += 8) { // eight tiles per OR
-                unsigned long long a, b_;
-                std::memcpy(&a, row + ti_, 8);
-                std::memcpy(&b_, cov[0].data() + ti_, 8);
-                a |= b_;
-                std::memcpy(row + ti_, &a, 8);
-              }
-              for (; ti_ < nt1; ti_++) row[ti_] |= cov[0][ti_];
+        };
+        size_t total = 0;
+        for (int b = 0; b < nb; b++) {
+          if (run[b].nbox == 0) continue;
+          covered(b);
+          for (int tk : cov[2])
+            for (int tj_ : cov[1]) {
+              int *row = &cnt[((size_t)tk * nt2 + tj_) * nt1];
+              for (int ti_ : cov[0]) row[ti_]++;
             }
-          }
+          total += cov[0].size() * cov[1].size() * cov[2].size();
         }
-        int *list = c->h_tiles[set];
-        int cnt = 0;
-        for (int t = 0; t < nblk; t++)
-          if (mark[t]) list[cnt++] = t;
-        if (cnt == 0) { list[0] = 0; cnt = 1; }
-        HIPCHK(c, hipMemcpyAsync(c->d_tiles[set], list, sizeof(int) * (size_t)cnt, hipMemcpyHostToDevice, c->stream2));
+        if (ensure_pair<int>(c, &c->d_tsrc[set], &c->h_tsrc[set], &c->tsrc_cap[set], total + 1)) return 1;
+        int *list = c->h_tiles[set], *tp = c->h_tptr[set], *tsrc = c->h_tsrc[set];
+        int ntl = 0;
+        size_t acc = 0;
+        for (int t = 0; t < nblk; t++) {
+          if (!cnt[t]) { cnt[t] = -1; continue; }
+          list[ntl] = t;
+          tp[ntl] = (int)acc;
+          acc += (size_t)cnt[t];
+          cnt[t] = ntl++; // from count to position in the list
+        }
+        if (ntl == 0) { list[0] = 0; tp[0] = 0; ntl = 1; }
+        tp[ntl] = (int)acc;
+        std::vector<int> fill(tp, tp + ntl);
+        for (int b = 0; b < nb; b++) { // ascending b: every tile's sources end up in source order
+          if (run[b].nbox == 0) continue;
+          covered(b);
+          for (int tk : cov[2])
+            for (int tj_ : cov[1]) {
+              const int *row = &cnt[((size_t)tk * nt2 + tj_) * nt1];
+              for (int ti_ : cov[0]) tsrc[fill[row[ti_]]++] = b;
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_tiles[set], list, sizeof(int) * (size_t)ntl, hipMemcpyHostToDevice, c->stream2));
+        HIPCHK(c, hipMemcpyAsync(c->d_tptr[set], tp, sizeof(int) * (size_t)(ntl + 1), hipMemcpyHostToDevice, c->stream2));
+        if (acc > 0) HIPCHK(c, hipMemcpyAsync(c->d_tsrc[set], tsrc, sizeof(int) * acc, hipMemcpyHostToDevice, c->stream2));
         d_tiles = c->d_tiles[set];
-        nblk = cnt;
+        d_tptr = c->d_tptr[set];
+        d_tsrc = c->d_tsrc[set];
+        nblk = ntl;
       }
     }
 #define C2R_LAUNCH_RATES(H, M)                                                                               \
-  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), 0, st_, g, ba, sc, c->d_ndens,  \
-                     c->d_xh_av, c->d_xhe_av, c->d_col, c->d_bands, ss, c->d_rates, d_tiles, base_)
-    const bool last_batch = b0 + c->batch >= mine.size();
+  hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), 0, st_, g, c->d_src[set], nb, sc, c->d_ndens, c->d_xh_av, \
+                     c->d_xhe_av, c->d_arena, c->d_bands, ss, c->d_rates, d_tiles, d_tptr, d_tsrc, base_)
+    const bool last_batch = b0 + nb >= mine.size();
     const int pieces = (last_batch && ns_eff > 0) ? ns_eff : 1;
     const int per_layer = nt1 * nt2;
     // slabs alternate between two streams so that the thin tail of one launch overlaps the start of the
@@ -1722,15 +1898,42 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     }
     HIPCHK(c, hipEventRecord(c->ev_rates_done[set], c->stream2));
     c->set_busy[set] = true;
+
+    // The losses that are kept but decided nothing (rounds that were a source's last for geometric reasons),
+    // one launch per final round, on the sweep stream while the rates run on theirs.
+    for (;;) {
+      int fr = -1;
+      for (int b = 0; b < nb; b++)
+        if (run[b].final_loss_due) { fr = run[b].nbox; break; }
+      if (fr < 0) break;
+      int *fl = hl + list_used;
+      int nf = 0;
+      for (int b = 0; b < nb; b++)
+        if (run[b].final_loss_due && run[b].nbox == fr) fl[nf++] = b;
+      HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, fl, sizeof(int) * nf, hipMemcpyHostToDevice, c->stream));
+      const Box fb = round_box(reach, fr);
+      const int f_lo = fr > 1 ? box_smax(round_box(reach, fr - 1)) + 1 : 0;
+      if (boundary_loss(c, set, list_used, nf, f_lo, box_smax(fb), fb, 1, sc, ss, multi)) return 1;
+      for (int j = 0; j < nf; j++) {
+        run[fl[j]].loss = c->h_loss[j];
+        run[fl[j]].final_loss_due = false;
+      }
+      list_used += (size_t)nf;
+    }
     // photon_loss(1) += photon_loss_src ; sum_nbox += nbox  (evolve_source.F90:233-236), source order
     for (int b = 0; b < nb; b++) {
       c->photon_loss[0] = c->photon_loss[0] + run[b].loss;
       c->sum_nbox += run[b].nbox;
     }
-    c->last_slot = slot0 + nb - 1;
+    c->tm.cells_swept += batch_cells;
     c->last_src = run[nb - 1].ns;
-    for (int d = 0; d < 3; d++) { c->last_lo[d] = run[nb - 1].last_l[d]; c->last_hi[d] = run[nb - 1].last_r[d]; }
-    if (run[nb - 1].nbox == 0) { c->last_lo[0] = 1; c->last_hi[0] = 0; } // nothing traced: all columns read as 0
+    c->last_col = c->h_src[set][nb - 1].col;
+    c->last_cz = c->h_src[set][nb - 1].cz;
+    {
+      const SrcDev &S = c->h_src[set][nb - 1];
+      for (int d = 0; d < 3; d++) { c->last_lo[d] = S.lo[d]; c->last_hi[d] = S.hi[d]; }
+    }
+    b0 += (size_t)nb;
   }
   // a rank without sources of its own still owes the caller its slab events
   if (mine.empty())
@@ -2061,17 +2264,17 @@ extern "C" int c2r_upload_iter_state(c2r_ctx *c, const double *xh_av, const doub
 
 extern "C" int c2r_download_columns(c2r_ctx *c, double *coldensh_out, double *coldenshe_out) {
   if (!c) return 1;
-  if (!c->d_col || c->last_src < 1) return fail(c, "c2r_download_columns: no source has been swept yet");
+  if (!c->d_arena || c->last_src < 1) return fail(c, "c2r_download_columns: no source has been swept yet");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
   if (!c->d_colgrid) HIPCHK(c, hipMalloc(&c->d_colgrid, sizeof(double) * 3 * nc));
   const int *p = &c->srcpos[3 * (size_t)(c->last_src - 1)];
   const int nblk = (int)((nc + BLOCK - 1) / BLOCK);
-  SrcInfo S{};
+  SrcDev S{};
   S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
   for (int d = 0; d < 3; d++) { S.lo[d] = c->last_lo[d]; S.hi[d] = c->last_hi[d]; }
-  hipLaunchKernelGGL(k_col_to_grid, dim3(nblk), dim3(BLOCK), 0, c->stream, c->g, S,
-                     c->d_col + (size_t)c->last_slot * 6 * c->g.colsize, c->d_colgrid);
+  S.cz = c->last_cz;
+  hipLaunchKernelGGL(k_col_to_grid, dim3(nblk), dim3(BLOCK), 0, c->stream, c->g, S, c->d_arena + c->last_col, c->d_colgrid);
   HIPCHK(c, hipGetLastError());
   if (coldensh_out) HIPCHK(c, hipMemcpyAsync(coldensh_out, c->d_colgrid, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
   if (coldenshe_out)

@@ -163,8 +163,10 @@ C2R_MHD Log10Arg log10_split(double x) { // x positive, normal, finite
   a.lo = (uint32_t)ix;
   const int k = (int)(hi >> 20) - 1023;
   const int i = (int)((uint32_t)k >> 31);
-  a.hx = (hi & 0x000FFFFFu) | ((uint32_t)(0x3ff - i) << 20);
   a.ky = k + i;
+  // (hi & 0xFFFFF) | (0x3ff - i) << 20: the sign bit is clear, so taking k + i out of the exponent field is a
+  // plain subtraction
+  a.hx = hi - ((uint32_t)a.ky << 20);
   return a;
 }
 C2R_MHD bool log10_near1(const Log10Arg &a) { return a.hx - 0x3FEE0000u < 0x00030900u; }
