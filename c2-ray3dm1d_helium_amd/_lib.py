@@ -83,6 +83,17 @@ SYMBOLS = {
     "c2r_set_rates_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "c2r_synchronize": (C.c_int, [C.c_void_p]),
     "c2r_set_batch": (C.c_int, [C.c_void_p, C.c_int]),
+    "c2r_device_count": (C.c_int, []),
+    "c2r_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _ip, _ip]),
+    "c2r_num_devices": (C.c_int, [C.c_void_p]),
+    "c2r_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "c2r_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
+    "c2r_comm_init_local": (C.c_int, [C.c_void_p]),
+    "c2r_comm_destroy": (C.c_int, [C.c_void_p]),
+    "c2r_comm_rank": (C.c_int, [C.c_void_p]),
+    "c2r_comm_nranks": (C.c_int, [C.c_void_p]),
+    "c2r_allreduce_rates": (C.c_int, [C.c_void_p]),
+    "c2r_pass_allreduce_chemistry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _ip]),
     "c2r_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "c2r_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
 }

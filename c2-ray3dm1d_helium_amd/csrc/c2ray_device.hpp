@@ -117,6 +117,9 @@ struct BandData {
   double f1heat_HI[NFREQ - 1], f1heat_HeI[NFREQ - 1], f1heat_HeII[NFREQ - 1];
   double f2heat_HI[NFREQ - 1], f2heat_HeI[NFREQ - 1], f2heat_HeII[NFREQ - 1];
   int bb_upper;
+  // per SED (black body, power law, quasar) and band: the optical depth from which every table entry a lookup
+  // of that band can touch is exactly 0 (band_tau_zero); +inf when there is no such depth
+  double tau_zero[3][NFREQ];
 };
 
 C2R_HD double dmax(double a, double b) { return a > b ? a : b; }
@@ -472,6 +475,21 @@ C2R_HD double read_table(const double *col, const TauPos &p) {
   return a + (b - a) * p.residual;
 }
 
+// Beyond some optical depth the tables of a band hold exact zeros (the integrands of radiation_tables.f90:471
+// are cut at tau*s(nu) >= 700): every rate of the band is then +0, and adding it changes no sum.  In neutral gas
+// behind an ionisation front that is most bands of most cells.  Given the band's columns (pitch NTAUP, `ncols` of
+// them: photo thick and thin, and its heating columns if there are any) this returns a depth X such that
+// tau >= X puts the table position at or beyond the last non-zero entry of all of them: one table step above
+// the exact boundary, so that no rounding of the log can matter.  Host side, once per table set.
+inline double band_tau_zero(const double *const *cols, int ncols) {
+  int z = 0; // first row from which all columns are zero
+  for (int c = 0; c < ncols; c++)
+    for (int r = NTAU + 1; r >= z; r--)
+      if (cols[c][r] != 0.0) { z = r + 1; break; }
+  if (z > NTAU) return (double)INFINITY;
+  return pow(10.0, minlogtau + (double)z * dlogtau);
+}
+
 struct PhotoOut {
   double photo_HI, photo_HeI, photo_HeII; // cell rates (before division by neutral densities)
   double heat;
@@ -563,10 +581,13 @@ struct SedSums {
 // +NumBndin2 (HI and HeI), 2: the bands above the He II threshold (all three species).  The cross sections of
 // species that cannot absorb in a band are exactly 0 (radiation_sizes.f90:382-383, :405; checked when the
 // tables are set), so their terms -- x*0 + ... with finite x -- are left out: the sums keep their bits.
+// `look_for_zero`: test whether the band is beyond the last non-zero table entry (band_tau_zero); returns
+// whether it was.  Within a class the optical depth falls from band to band, so once no lane of a wave has
+// found a band dead the caller stops asking (a missed skip costs time, never a bit).
 template <bool HEAT, int CLS>
-C2R_HD void band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
-                       const double *heat_thin, const double *logtab, int b, const CellSrc &c, const Ricotti &ric,
-                       SedSums &o) {
+C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
+                       const double *heat_thin, const double *logtab, const double *tau_zero, bool look_for_zero, int b,
+                       const CellSrc &c, const Ricotti &ric, SedSums &o) {
   const double NFlux = c.NFlux;
   const double sHI = bd.sigma_HI[b];
   double sHeI = 0.0, sHeII = 0.0;
@@ -580,6 +601,12 @@ C2R_HD void band_rates(const BandData &bd, const double *photo_thick, const doub
     sHeII = bd.sigma_HeII[b];
     tau_in = tau_in + c.cin_HeII * sHeII;
     tau_out = tau_out + c.cout_HeII * sHeII;
+  }
+  if (look_for_zero && tau_in >= tau_zero[b]) {
+    // every table entry this band would read is exactly 0 (tau_out >= tau_in): all its rates are +0 and no sum
+    // changes; what the reference's band would leave behind in df_ion is +0 as well
+    if (HEAT && CLS >= 1) o.df_ion_HI = o.df_ion_HeI = 0.0;
+    return true;
   }
   const double dtau = tau_out - tau_in;
   const bool thick = fabs(dtau) > tau_photo_limit;
@@ -721,7 +748,15 @@ C2R_HD void band_rates(const BandData &bd, const double *photo_thick, const doub
     o.f_ion_HI = o.f_ion_HI + o.df_ion_HI;
     o.f_ion_HeI = o.f_ion_HeI + o.df_ion_HeI;
   }
+  return false;
 }
+
+// true if the predicate holds in any lane of the wave (on the host: for this one evaluation)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool any_lane(bool p) { return __any(p ? 1 : 0) != 0; }
+#else
+inline bool any_lane(bool p) { return p; }
+#endif
 
 // what one photo_lookuptable + heat_lookuptable pair of calls returns for one SED (before the sums of
 // radiation_photoionrates.f90:178-262 put them together)
@@ -738,7 +773,7 @@ template <bool HEAT>
 C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                       const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
                       double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                      double NFlux, const Ricotti &ric, SedAcc &out, const double *logtab) {
+                      double NFlux, const Ricotti &ric, SedAcc &out, const double *logtab, const double *tau_zero) {
   out.photo_HI = out.photo_HeI = out.photo_HeII = 0.0;
   out.photo_out = 0.0;
   out.f_heat = out.f_ion_HI = out.f_ion_HeI = 0.0;
@@ -755,9 +790,15 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
   SedSums o = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const int e0 = bhi < NB1 ? bhi : NB1, e1 = bhi < NB1 + NB2 ? bhi : NB1 + NB2;
   int b = blo;
-  for (; b < e0; b++) band_rates<HEAT, 0>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, b, c, ric, o);
-  for (; b < e1; b++) band_rates<HEAT, 1>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, b, c, ric, o);
-  for (; b < bhi; b++) band_rates<HEAT, 2>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, b, c, ric, o);
+  bool look = true;
+  for (; b < e0; b++)
+    look = any_lane(band_rates<HEAT, 0>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o));
+  look = true;
+  for (; b < e1; b++)
+    look = any_lane(band_rates<HEAT, 1>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o));
+  look = true;
+  for (; b < bhi; b++)
+    look = any_lane(band_rates<HEAT, 2>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o));
   out.photo_HI = o.photo_HI;
   out.photo_HeI = o.photo_HeI;
   out.photo_HeII = o.photo_HeII;
@@ -778,7 +819,7 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
                            double NFlux, const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT) {
   SedAcc a;
   sed_rates<HEAT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
-                  cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab);
+                  cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab, bd.tau_zero[0]);
   o.photo_HI = a.photo_HI;
   o.photo_HeI = a.photo_HeI;
   o.photo_HeII = a.photo_HeII;
@@ -819,7 +860,7 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
     act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
     if (act[s])
       sed_rates<HEAT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
-                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab);
+                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s]);
   }
   // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
   for (int s = 0; s < NSED; s++) {
@@ -848,6 +889,7 @@ C2R_HD double photo_out_multi(const BandData &bd, const SedSet &ss, double cin_H
     for (int b = ss.lo[s]; b < ss.hi[s]; b++) {
       const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
       const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+      if (tau_in >= bd.tau_zero[s][b]) continue; // phi_out = +0 exactly (band_tau_zero)
       const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
       const double *tk = ss.photo_thick[s] + (size_t)b * NTAUP;
       double phi_out;
@@ -880,6 +922,7 @@ C2R_HD double photo_out_only(const BandData &bd, const double *photo_thick, cons
   for (int b = 0; b < nb; b++) {
     const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
     const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+    if (tau_in >= bd.tau_zero[0][b]) continue; // phi_out = +0 exactly (band_tau_zero)
     const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
     const double *tk = photo_thick + (size_t)b * NTAUP;
     double phi_out;

@@ -742,12 +742,20 @@ k_stat_finish(const double *__restrict__ partial, int nblocks, double *__restric
 // host side
 struct c2r_ctx {
   int device = 0;
+  std::vector<c2r_ctx *> replicas; // further devices of a context made by c2r_create_multi (each a plain context)
+  // sum over ranks (c2ray_comm.inc): kind 0 none, 1 RCCL, 2 in-process sum for replicas that share a device
+  int comm_kind = 0, comm_rank = 0, comm_nranks = 1;
+  void *comm = nullptr;            // ncclComm_t
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_comm_a = nullptr, ev_comm_b = nullptr;
+  std::vector<hipEvent_t> ev_sum;  // slab s of the rate grids is summed over the ranks
   hipStream_t stream = nullptr;
   Grid g{};
   std::string err;
 
   double *d_photo_thick = nullptr, *d_photo_thin = nullptr, *d_heat_thick = nullptr, *d_heat_thin = nullptr;
   BandData *d_bands = nullptr;
+  BandData h_bands{};              // host copy (tau_zero is refreshed whenever a table set changes)
   bool have_tables = false, have_heat_tables = false, have_bands = false, have_fvec = false;
   int bb_upper = 0;
   double *d_cool = nullptr;
@@ -787,6 +795,7 @@ struct c2r_ctx {
   // six copies).  Zeroed at allocation and only ever holding finite columns afterwards.
   double *d_arena = nullptr;
   size_t arena_half = 0;           // doubles per half
+  size_t arena_half_prev = 0;      // before the last growth
   size_t arena_used[2] = {0, 0};
   std::vector<int> prev_nbox;      // per source: sub-boxes of the last pass (0: unknown), sizes the next block
   SrcDev *d_src[2] = {nullptr, nullptr}, *h_src[2] = {nullptr, nullptr}; // source records of the two sets (h: pinned)
@@ -866,6 +875,18 @@ static int fail(c2r_ctx *c, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// a context made by c2r_create_multi drives further devices through `replicas` (plain one-device contexts)
+template <class F>
+static int for_replicas(c2r_ctx *c, F f) {
+  if (!c) return 0;
+  for (c2r_ctx *r : c->replicas)
+    if (int e = f(r)) {
+      c->err = "device " + std::to_string(r->device) + ": " + r->err;
+      return e;
+    }
+  return 0;
+}
+
 extern "C" const char *c2r_last_error(const c2r_ctx *c) { return c ? c->err.c_str() : "null context"; }
 extern "C" const char *c2r_create_error(void) { return g_create_error.c_str(); }
 
@@ -896,6 +917,7 @@ static int ensure_arena(c2r_ctx *c, size_t need_half, bool *grown) {
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   if (c->d_arena) HIPCHK(c, hipFree(c->d_arena));
   c->d_arena = nullptr;
+  c->arena_half_prev = c->arena_half;
   c->arena_half = 0;
   size_t free_b = 0, total_b = 0;
   HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
@@ -903,8 +925,9 @@ static int ensure_arena(c2r_ctx *c, size_t need_half, bool *grown) {
   if (need_half > limit)
     return fail(c, "column scratch: two halves of %.1f GB do not fit in %.1f GB of free device memory", need_half * 8e-9,
                 free_b / 1e9);
-  // some room to grow into, so that the next larger batch does not reallocate again
-  size_t want = std::min(limit, std::max(need_half + need_half / 2, (size_t)1 << 27));
+  // grows geometrically (an allocation of tens of GB takes of the order of a second): at least twice what
+  // there was and twice what is asked for now, within the limit
+  size_t want = std::min(limit, std::max(std::max(2 * need_half, 2 * c->arena_half_prev), (size_t)1 << 28));
   HIPCHK(c, hipMalloc(&c->d_arena, sizeof(double) * 2 * want));
   HIPCHK(c, zero_device(c->d_arena, sizeof(double) * 2 * want, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1021,7 +1044,14 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
 
 extern "C" void c2r_destroy(c2r_ctx *c) {
   if (!c) return;
+  (void)c2r_comm_destroy(c);
+  for (c2r_ctx *r : c->replicas) c2r_destroy(r);
+  c->replicas.clear();
   (void)hipSetDevice(c->device);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->ev_comm_a) (void)hipEventDestroy(c->ev_comm_a);
+  if (c->ev_comm_b) (void)hipEventDestroy(c->ev_comm_b);
+  for (auto &ev : c->ev_sum) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &row : c->d_sed_tab)
     for (double *p : row)
@@ -1072,7 +1102,42 @@ static int upload_table(c2r_ctx *c, const double *src, int ncol, double **dst) {
   return 0;
 }
 
-extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const double *photo_thin,
+// BandData::tau_zero of SED `sed` (0 black body, 1 power law, 2 quasar) from the tables now on the device
+// (uploaded or built there), and the band data to the device again.
+static int refresh_tau_zero(c2r_ctx *c, int sed) {
+  const double *tab[4] = {sed == 0 ? c->d_photo_thick : c->d_sed_tab[sed - 1][0], sed == 0 ? c->d_photo_thin : c->d_sed_tab[sed - 1][1],
+                          sed == 0 ? c->d_heat_thick : c->d_sed_tab[sed - 1][2], sed == 0 ? c->d_heat_thin : c->d_sed_tab[sed - 1][3]};
+  const bool have = sed == 0 ? c->have_tables : c->have_sed[sed - 1];
+  const bool heat = sed == 0 ? c->have_heat_tables : c->have_sed_heat[sed - 1];
+  for (int b = 0; b < NFREQ; b++) c->h_bands.tau_zero[sed][b] = (double)INFINITY;
+  if (have) {
+    std::vector<double> h[4];
+    const int ncol[4] = {NFREQ, NFREQ, NHEAT, NHEAT};
+    for (int t = 0; t < (heat ? 4 : 2); t++) {
+      h[t].resize((size_t)ncol[t] * NTAUP);
+      HIPCHK(c, hipMemcpy(h[t].data(), tab[t], sizeof(double) * h[t].size(), hipMemcpyDeviceToHost));
+    }
+    for (int b = 0; b < NFREQ; b++) {
+      const double *cols[8];
+      int n = 0;
+      cols[n++] = &h[0][(size_t)b * NTAUP];
+      cols[n++] = &h[1][(size_t)b * NTAUP];
+      if (heat) {
+        const int nh = b < NB1 ? 1 : (b < NB1 + NB2 ? 2 : 3);
+        const int c0 = b < NB1 ? 0 : (b < NB1 + NB2 ? 2 * (b + 1) - NB1 - 2 : 3 * (b + 1) - NB2 - 2 * NB1 - 3);
+        for (int k = 0; k < nh; k++) {
+          cols[n++] = &h[2][(size_t)(c0 + k) * NTAUP];
+          cols[n++] = &h[3][(size_t)(c0 + k) * NTAUP];
+        }
+      }
+      c->h_bands.tau_zero[sed][b] = band_tau_zero(cols, n);
+    }
+  }
+  if (c->have_bands) HIPCHK(c, hipMemcpy(c->d_bands, &c->h_bands, sizeof(BandData), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int set_tables_one(c2r_ctx *c, const double *photo_thick, const double *photo_thin,
                               const double *heat_thick, const double *heat_thin, const double *sigma_HI,
                               const double *sigma_HeI, const double *sigma_HeII, const double *const fvec[12],
                               int bb_upper) {
@@ -1126,13 +1191,18 @@ extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const doubl
     c->have_fvec = true;
     c->have_heat_tables = heat_thick != nullptr;
   }
-  HIPCHK(c, hipMemcpy(c->d_bands, &bd, sizeof bd, hipMemcpyHostToDevice));
+  for (int sd = 0; sd < 3; sd++) // the other SEDs keep theirs
+    std::memcpy(bd.tau_zero[sd], c->h_bands.tau_zero[sd], sizeof bd.tau_zero[sd]);
+  if (!c->have_bands)
+    for (int sd = 0; sd < 3; sd++)
+      for (int b = 0; b < NFREQ; b++) bd.tau_zero[sd][b] = (double)INFINITY;
+  c->h_bands = bd;
   c->bb_upper = bb_upper;
   c->have_bands = true;
-  return 0;
+  return refresh_tau_zero(c, 0); // uploads the band data too
 }
 
-extern "C" int c2r_set_cooling(c2r_ctx *c, const double *cool, double mintemp, double dtemp) {
+static int set_cooling_one(c2r_ctx *c, const double *cool, double mintemp, double dtemp) {
   if (!c) return 1;
   if (!cool || !(dtemp > 0.0)) return fail(c, "c2r_set_cooling: bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1144,7 +1214,7 @@ extern "C" int c2r_set_cooling(c2r_ctx *c, const double *cool, double mintemp, d
   return 0;
 }
 
-extern "C" int c2r_set_step(c2r_ctx *c, const double *ndens, const double dr[3], double vol, float clumping,
+static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], double vol, float clumping,
                             double zred, double H0, double Omega0, int isothermal, double temper_val,
                             const double reccoef[12]) {
   if (!c) return 1;
@@ -1162,7 +1232,7 @@ extern "C" int c2r_set_step(c2r_ctx *c, const double *ndens, const double dr[3],
   return 0;
 }
 
-extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const double *normflux, double s_star) {
+static int set_sources_one(c2r_ctx *c, int nsrc, const int *srcpos, const double *normflux, double s_star) {
   if (!c) return 1;
   if (nsrc < 0 || (nsrc > 0 && (!srcpos || !normflux))) return fail(c, "c2r_set_sources: bad arguments");
   for (int s = 0; s < nsrc; s++) {
@@ -1180,7 +1250,7 @@ extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const do
   return 0;
 }
 
-extern "C" int c2r_set_sed_tables(c2r_ctx *c, int sed, const double *photo_thick, const double *photo_thin,
+static int set_sed_tables_one(c2r_ctx *c, int sed, const double *photo_thick, const double *photo_thin,
                                   const double *heat_thick, const double *heat_thin, int lower, int upper) {
   if (!c) return 1;
   if (sed < 1 || sed > 2) return fail(c, "c2r_set_sed_tables: sed = %d, expected 1 (power law) or 2 (quasar)", sed);
@@ -1205,10 +1275,10 @@ extern "C" int c2r_set_sed_tables(c2r_ctx *c, int sed, const double *photo_thick
   c->sed_lo[k] = lower - 1;
   c->sed_hi[k] = upper;
   c->have_sed[k] = true;
-  return 0;
+  return refresh_tau_zero(c, sed);
 }
 
-extern "C" int c2r_set_sources_sed(c2r_ctx *c, int sed, const double *normflux, double s_star) {
+static int set_sources_sed_one(c2r_ctx *c, int sed, const double *normflux, double s_star) {
   if (!c) return 1;
   if (sed < 1 || sed > 2) return fail(c, "c2r_set_sources_sed: sed = %d, expected 1 or 2", sed);
   const int k = sed - 1;
@@ -1250,7 +1320,7 @@ static void build_sed_vectors(const c2r_sed_setup &S, std::vector<double> &v) {
   }
 }
 
-extern "C" int c2r_build_tables(c2r_ctx *c, const c2r_sed_setup *S, int with_heat) {
+static int build_tables_one(c2r_ctx *c, const c2r_sed_setup *S, int with_heat) {
   if (!c || !S) return 1;
   if (S->nfreq != 512) return fail(c, "c2r_build_tables: nfreq = %d, the band set-up is for NumFreq = 512", S->nfreq);
   if (S->sed < 0 || S->sed > 2) return fail(c, "c2r_build_tables: sed = %d, expected 0 (black body), 1 (power law), 2 (quasar)", S->sed);
@@ -1261,9 +1331,13 @@ extern "C" int c2r_build_tables(c2r_ctx *c, const c2r_sed_setup *S, int with_hea
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<double> v;
   build_sed_vectors(*S, v);
-  double *d_v = nullptr, *d_small = nullptr;
-  HIPCHK(c, hipMalloc(&d_v, sizeof(double) * v.size()));
-  HIPCHK(c, hipMalloc(&d_small, sizeof(double) * (NTAU + 1 + 513 + NFREQ)));
+  struct DevBuf { // freed on every way out, the error returns included
+    double *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+  } buf_v, buf_small;
+  HIPCHK(c, hipMalloc(&buf_v.p, sizeof(double) * v.size()));
+  HIPCHK(c, hipMalloc(&buf_small.p, sizeof(double) * (NTAU + 1 + 513 + NFREQ)));
+  double *d_v = buf_v.p, *d_small = buf_small.p;
   HIPCHK(c, hipMemcpy(d_v, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(d_small, S->tau, sizeof(double) * (NTAU + 1), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(d_small + NTAU + 1, S->romw, sizeof(double) * 513, hipMemcpyHostToDevice));
@@ -1282,8 +1356,6 @@ extern "C" int c2r_build_tables(c2r_ctx *c, const c2r_sed_setup *S, int with_hea
                      with_heat ? *ht : nullptr, with_heat ? *hn : nullptr);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_v);
-  (void)hipFree(d_small);
   if (S->sed == 0) {
     c->have_tables = true;
     c->have_heat_tables = with_heat != 0;
@@ -1291,7 +1363,7 @@ extern "C" int c2r_build_tables(c2r_ctx *c, const c2r_sed_setup *S, int with_hea
     c->have_sed[S->sed - 1] = true;
     c->have_sed_heat[S->sed - 1] = with_heat != 0;
   }
-  return 0;
+  return refresh_tau_zero(c, S->sed);
 }
 
 extern "C" int c2r_download_tables(c2r_ctx *c, int sed, double *photo_thick, double *photo_thin, double *heat_thick,
@@ -1317,7 +1389,7 @@ extern "C" int c2r_download_tables(c2r_ctx *c, int sed, double *photo_thick, dou
   return 0;
 }
 
-extern "C" int c2r_set_lls(c2r_ctx *c, int use_lls, double coldensh_lls, const float *lls_grid) {
+static int set_lls_one(c2r_ctx *c, int use_lls, double coldensh_lls, const float *lls_grid) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   c->sc.use_lls = use_lls ? 1 : 0;
@@ -1332,7 +1404,7 @@ extern "C" int c2r_set_lls(c2r_ctx *c, int use_lls, double coldensh_lls, const f
   return 0;
 }
 
-extern "C" int c2r_set_clumping_grid(c2r_ctx *c, const float *clumping_grid) {
+static int set_clumping_grid_one(c2r_ctx *c, const float *clumping_grid) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   c->clumping_on_grid = false;
@@ -1345,7 +1417,7 @@ extern "C" int c2r_set_clumping_grid(c2r_ctx *c, const float *clumping_grid) {
   return 0;
 }
 
-extern "C" int c2r_upload_state(c2r_ctx *c, const double *xh, const double *xhe, const float *temperature) {
+static int upload_state_one(c2r_ctx *c, const double *xh, const double *xhe, const float *temperature) {
   if (!c) return 1;
   if (!xh || !xhe) return fail(c, "c2r_upload_state: null argument");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1417,7 +1489,7 @@ static StepScalars scalars(c2r_ctx *c) {
   return s;
 }
 
-extern "C" int c2r_begin_step(c2r_ctx *c) {
+static int begin_step_one(c2r_ctx *c) {
   if (!c) return 1;
   if (!c->have_state) return fail(c, "c2r_begin_step: c2r_upload_state has not been called");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1429,7 +1501,7 @@ extern "C" int c2r_begin_step(c2r_ctx *c) {
   return 0;
 }
 
-extern "C" int c2r_end_step(c2r_ctx *c) {
+static int end_step_one(c2r_ctx *c) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
@@ -1440,7 +1512,7 @@ extern "C" int c2r_end_step(c2r_ctx *c) {
   return 0;
 }
 
-extern "C" int c2r_set_rates_to_zero(c2r_ctx *c) {
+static int set_rates_to_zero_one(c2r_ctx *c) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, zero_device(c->d_rates, sizeof(double) * c->rates_count, c->stream));
@@ -1449,7 +1521,7 @@ extern "C" int c2r_set_rates_to_zero(c2r_ctx *c) {
   return 0;
 }
 
-extern "C" int c2r_set_batch(c2r_ctx *c, int nbatch) {
+static int set_batch_one(c2r_ctx *c, int nbatch) {
   if (!c) return 1;
   if (nbatch < 1 || nbatch > BATCH_MAX) return fail(c, "c2r_set_batch: %d not in [1,%d]", nbatch, BATCH_MAX);
   c->batch = nbatch;
@@ -1690,10 +1762,15 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         const int ncap = std::min(g.smax, std::max(s_hi, 2 * r.cap));
         const size_t nd = block_doubles(ncap);
         if (c->arena_used[set] + nd > c->arena_half) {
-          // out of room in the middle of a sweep: nothing of this batch has reached the rate grids yet, so the
-          // batch starts over with blocks for the whole mesh (and fewer sources if need be)
+          // Out of room in the middle of a sweep.  Nothing of this batch has reached the rate grids yet, so the
+          // batch starts over with what this attempt has taught: sources that have stopped get the block they
+          // needed, those still growing twice the rounds they have come to (the sizing loop then grows the
+          // arena, or shrinks the batch).  Each restart at least doubles the blocks of the growing sources.
           HIPCHK(c, hipStreamSynchronize(c->stream));
-          full_caps = true;
+          for (int b = 0; b < nb; b++) {
+            int &pn = c->prev_nbox[(size_t)run[b].ns - 1];
+            pn = std::max(pn, run[b].active ? 2 * run[b].nbox : run[b].nbox);
+          }
           goto restart_batch;
         }
         SrcDev &S = c->h_src[set][act[a]];
@@ -1967,8 +2044,7 @@ static int pass_finish(c2r_ctx *c) {
   return 0;
 }
 
-extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
-  if (!c) return 1;
+static int pass_sources_one(c2r_ctx *c, int first, int stride) {
   if (check_ready(c, "c2r_pass_sources")) return 1;
   if (first < 1 || stride < 1) return fail(c, "c2r_pass_sources: first=%d stride=%d", first, stride);
   std::vector<int> mine;
@@ -1978,6 +2054,7 @@ extern "C" int c2r_pass_sources(c2r_ctx *c, int first, int stride) {
 
 extern "C" int c2r_pass_sources_begin(c2r_ctx *c, int first, int stride, int nslab) {
   if (!c) return 1;
+  if (!c->replicas.empty()) return fail(c, "c2r_pass_sources_begin: not available on a multi-device context");
   if (check_ready(c, "c2r_pass_sources_begin")) return 1;
   if (first < 1 || stride < 1 || nslab < 1) return fail(c, "c2r_pass_sources_begin: first=%d stride=%d nslab=%d", first, stride, nslab);
   std::vector<int> mine;
@@ -2006,6 +2083,7 @@ extern "C" int c2r_pass_sources_end(c2r_ctx *c) {
 
 extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
   if (!c) return 1;
+  if (!c->replicas.empty()) return fail(c, "c2r_do_source: not available on a multi-device context");
   if (check_ready(c, "c2r_do_source")) return 1;
   if (ns < 1 || ns > c->nsrc) return fail(c, "c2r_do_source: source %d not in [1,%d]", ns, c->nsrc);
   return pass_list(c, std::vector<int>{ns});
@@ -2166,36 +2244,9 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
   return 0;
 }
 
-extern "C" int c2r_global_pass(c2r_ctx *c, double dt, int *conv_flag) {
-  if (!c) return 1;
+static int global_pass_one(c2r_ctx *c, double dt, int *conv_flag) {
   if (c2r_global_pass_cells(c, dt, 0, c->g.ncell, nullptr)) return 1;
   return c2r_global_pass_finish(c, conv_flag);
-}
-
-extern "C" int c2r_evolve3d(c2r_ctx *c, double dt, int *niter_out, int *conv_flags_out, int cap) {
-  if (!c) return 1;
-  if (check_ready(c, "c2r_evolve3d")) return 1;
-  if (c2r_begin_step(c)) return 1;
-  int niter = 0;
-  const Grid g = c->g;
-  int conv_flag = (int)g.ncell;
-  const int conv_criterion = std::min((int)(convergence_fraction * g.n1 * g.n2 * g.n3), c->nsrc); // evolve.F90:147
-  for (;;) {
-    if (conv_flag < conv_criterion && niter > 1) { // evolve.F90:163
-      if (c2r_end_step(c)) return 1;
-      break;
-    } else if (niter > 500) {
-      break;
-    }
-    niter++;
-    if (c2r_set_rates_to_zero(c)) return 1;
-    if (c->nsrc > 0 && c2r_pass_sources(c, 1, 1)) return 1;
-    if (c2r_global_pass(c, dt, &conv_flag)) return 1;
-    if (conv_flags_out && niter <= cap) conv_flags_out[niter - 1] = conv_flag;
-  }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (niter_out) *niter_out = niter;
-  return 0;
 }
 
 extern "C" int c2r_download_rates(c2r_ctx *c, double *phih, double *phihe, double *phiheat, double *photon_loss47,
@@ -2236,7 +2287,7 @@ extern "C" int c2r_download_iter_state(c2r_ctx *c, double *xh_av, double *xhe_av
   return 0;
 }
 
-extern "C" int c2r_upload_rates(c2r_ctx *c, const double *phih, const double *phihe, const double *phiheat) {
+static int upload_rates_one(c2r_ctx *c, const double *phih, const double *phihe, const double *phiheat) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
@@ -2247,7 +2298,7 @@ extern "C" int c2r_upload_rates(c2r_ctx *c, const double *phih, const double *ph
   return 0;
 }
 
-extern "C" int c2r_upload_iter_state(c2r_ctx *c, const double *xh_av, const double *xhe_av, const double *xh_intermed,
+static int upload_iter_state_one(c2r_ctx *c, const double *xh_av, const double *xhe_av, const double *xh_intermed,
                                      const double *xhe_intermed) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2358,13 +2409,13 @@ extern "C" int c2r_set_rates_buffer(c2r_ctx *c, void *device_ptr, size_t count) 
   c->d_rates = (double *)device_ptr;
   return 0;
 }
-extern "C" int c2r_synchronize(c2r_ctx *c) {
+static int synchronize_one(c2r_ctx *c) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-extern "C" int c2r_enable_timing(c2r_ctx *c, int on) {
+static int enable_timing_one(c2r_ctx *c, int on) {
   if (!c) return 1;
   c->timing = on != 0;
   return 0;
@@ -2374,3 +2425,97 @@ extern "C" int c2r_get_timing(c2r_ctx *c, c2r_timing *out) {
   *out = c->tm;
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// state-setting entry points: the same call on every device of a multi-device context
+extern "C" int c2r_set_tables(c2r_ctx *c, const double *photo_thick, const double *photo_thin, const double *heat_thick, const double *heat_thin, const double *sigma_HI, const double *sigma_HeI, const double *sigma_HeII, const double *const fvec[12], int bb_upper) {
+  if (int e_ = set_tables_one(c, photo_thick, photo_thin, heat_thick, heat_thin, sigma_HI, sigma_HeI, sigma_HeII, fvec, bb_upper)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_tables_one(r, photo_thick, photo_thin, heat_thick, heat_thin, sigma_HI, sigma_HeI, sigma_HeII, fvec, bb_upper); });
+}
+
+extern "C" int c2r_set_cooling(c2r_ctx *c, const double *cool, double mintemp, double dtemp) {
+  if (int e_ = set_cooling_one(c, cool, mintemp, dtemp)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_cooling_one(r, cool, mintemp, dtemp); });
+}
+
+extern "C" int c2r_set_step(c2r_ctx *c, const double *ndens, const double dr[3], double vol, float clumping, double zred, double H0, double Omega0, int isothermal, double temper_val, const double reccoef[12]) {
+  if (int e_ = set_step_one(c, ndens, dr, vol, clumping, zred, H0, Omega0, isothermal, temper_val, reccoef)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_step_one(r, ndens, dr, vol, clumping, zred, H0, Omega0, isothermal, temper_val, reccoef); });
+}
+
+extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const double *normflux, double s_star) {
+  if (int e_ = set_sources_one(c, nsrc, srcpos, normflux, s_star)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_sources_one(r, nsrc, srcpos, normflux, s_star); });
+}
+
+extern "C" int c2r_set_sed_tables(c2r_ctx *c, int sed, const double *photo_thick, const double *photo_thin, const double *heat_thick, const double *heat_thin, int lower, int upper) {
+  if (int e_ = set_sed_tables_one(c, sed, photo_thick, photo_thin, heat_thick, heat_thin, lower, upper)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_sed_tables_one(r, sed, photo_thick, photo_thin, heat_thick, heat_thin, lower, upper); });
+}
+
+extern "C" int c2r_set_sources_sed(c2r_ctx *c, int sed, const double *normflux, double s_star) {
+  if (int e_ = set_sources_sed_one(c, sed, normflux, s_star)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_sources_sed_one(r, sed, normflux, s_star); });
+}
+
+extern "C" int c2r_build_tables(c2r_ctx *c, const c2r_sed_setup *S, int with_heat) {
+  if (int e_ = build_tables_one(c, S, with_heat)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return build_tables_one(r, S, with_heat); });
+}
+
+extern "C" int c2r_set_lls(c2r_ctx *c, int use_lls, double coldensh_lls, const float *lls_grid) {
+  if (int e_ = set_lls_one(c, use_lls, coldensh_lls, lls_grid)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_lls_one(r, use_lls, coldensh_lls, lls_grid); });
+}
+
+extern "C" int c2r_set_clumping_grid(c2r_ctx *c, const float *clumping_grid) {
+  if (int e_ = set_clumping_grid_one(c, clumping_grid)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_clumping_grid_one(r, clumping_grid); });
+}
+
+extern "C" int c2r_upload_state(c2r_ctx *c, const double *xh, const double *xhe, const float *temperature) {
+  if (int e_ = upload_state_one(c, xh, xhe, temperature)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return upload_state_one(r, xh, xhe, temperature); });
+}
+
+extern "C" int c2r_begin_step(c2r_ctx *c) {
+  if (int e_ = begin_step_one(c)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return begin_step_one(r); });
+}
+
+extern "C" int c2r_end_step(c2r_ctx *c) {
+  if (int e_ = end_step_one(c)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return end_step_one(r); });
+}
+
+extern "C" int c2r_set_rates_to_zero(c2r_ctx *c) {
+  if (int e_ = set_rates_to_zero_one(c)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_rates_to_zero_one(r); });
+}
+
+extern "C" int c2r_set_batch(c2r_ctx *c, int nbatch) {
+  if (int e_ = set_batch_one(c, nbatch)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_batch_one(r, nbatch); });
+}
+
+extern "C" int c2r_upload_rates(c2r_ctx *c, const double *phih, const double *phihe, const double *phiheat) {
+  if (int e_ = upload_rates_one(c, phih, phihe, phiheat)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return upload_rates_one(r, phih, phihe, phiheat); });
+}
+
+extern "C" int c2r_upload_iter_state(c2r_ctx *c, const double *xh_av, const double *xhe_av, const double *xh_intermed, const double *xhe_intermed) {
+  if (int e_ = upload_iter_state_one(c, xh_av, xhe_av, xh_intermed, xhe_intermed)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return upload_iter_state_one(r, xh_av, xhe_av, xh_intermed, xhe_intermed); });
+}
+
+extern "C" int c2r_enable_timing(c2r_ctx *c, int on) {
+  if (int e_ = enable_timing_one(c, on)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return enable_timing_one(r, on); });
+}
+
+extern "C" int c2r_synchronize(c2r_ctx *c) {
+  if (int e_ = synchronize_one(c)) return e_;
+  return for_replicas(c, [&](c2r_ctx *r) { return synchronize_one(r); });
+}
+
+#include "c2ray_comm.inc"

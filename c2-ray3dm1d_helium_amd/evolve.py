@@ -138,7 +138,8 @@ class Cosmology:
 
 
 class HipEngine:
-    """Thin object wrapper over the C ABI (one context = one GPU)."""
+    """Thin object wrapper over the C ABI.  `device`: one GPU, or a list of GPUs driven by this process
+    (c2r_create_multi: every state-setting call goes to all of them, results are read from the first)."""
 
     def __init__(self, mesh, device=0):
         self.lib = _lib.load()
@@ -146,10 +147,48 @@ class HipEngine:
         self.ncell = int(np.prod(self.mesh))
         h = C.c_void_p()
         m = (C.c_int * 3)(*self.mesh)
-        if self.lib.c2r_create(C.byref(h), int(device), m) != 0:
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            rc = self.lib.c2r_create_multi(C.byref(h), len(device), devs, m)
+        else:
+            rc = self.lib.c2r_create(C.byref(h), int(device), m)
+        if rc != 0:
             raise C2RayHipError(self.lib.c2r_create_error().decode())
         self.h = h
         self._ext_rates = None
+
+    # -- several GPUs: the sum over ranks behind the C ABI (RCCL) ----------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId, for ONE rank to obtain and the launcher to pass to the others."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        if lib.c2r_comm_unique_id(buf) != 0:
+            raise C2RayHipError(lib.c2r_create_error().decode())
+        return buf.raw
+
+    def comm_init(self, first_rank, nranks, unique_id):
+        assert len(unique_id) == 128
+        self._chk(self.lib.c2r_comm_init(self.h, int(first_rank), int(nranks), unique_id))
+
+    def comm_init_local(self):
+        self._chk(self.lib.c2r_comm_init_local(self.h))
+
+    def comm_size(self):
+        return int(self.lib.c2r_comm_nranks(self.h))
+
+    def num_devices(self):
+        return int(self.lib.c2r_num_devices(self.h))
+
+    def allreduce_rates(self):
+        self._chk(self.lib.c2r_allreduce_rates(self.h))
+
+    def pass_allreduce_chemistry(self, dt, first=1, stride=1, nslab=4):
+        """pass_all_sources + sum over ranks + global pass of one outer iteration, overlapped slab by slab;
+        returns the non-converged count."""
+        cf = C.c_int(0)
+        self._chk(self.lib.c2r_pass_allreduce_chemistry(self.h, int(first), int(stride), int(nslab), float(dt), C.byref(cf)))
+        return cf.value
 
     def close(self):
         if getattr(self, "h", None):

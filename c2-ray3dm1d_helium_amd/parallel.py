@@ -107,6 +107,36 @@ class TorchComm:
         return engine.global_pass_finish()
 
 
+class RcclComm:
+    """One process per GPU, the sum over ranks inside the library (c2r_comm_init + ncclAllReduce): what
+    bench.py and a torch.distributed.run launch use.  torch.distributed only carries the 128-byte RCCL id from
+    rank 0 to the others (any backend) and the barrier / max-over-ranks of the timing harness; nothing of it is
+    in the data path."""
+
+    def __init__(self, engine, dist=None):
+        self.engine = engine
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.size = dist.get_world_size() if dist is not None else 1
+        uid = [type(engine).comm_unique_id() if self.rank == 0 else None]
+        if dist is not None and self.size > 1:
+            dist.broadcast_object_list(uid, src=0)
+        engine.comm_init(self.rank, self.size, uid[0])
+
+    def allreduce_rates(self, engine=None):
+        self.engine.allreduce_rates()
+
+    def pass_and_allreduce(self, engine=None, nslab=None):
+        self.engine.pass_sources(1 + self.rank, self.size)
+        self.engine.allreduce_rates()
+
+    def pass_allreduce_chemistry(self, engine, dt, nslab=None):
+        import os
+        if nslab is None:
+            nslab = int(os.environ.get("C2R_ALLREDUCE_SLABS", "4"))
+        return self.engine.pass_allreduce_chemistry(dt, 1 + self.rank, self.size, nslab)
+
+
 class SingleComm:
     rank, size = 0, 1
 

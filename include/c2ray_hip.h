@@ -213,8 +213,44 @@ void *c2r_rates_device_ptr(c2r_ctx *ctx);
 int c2r_set_rates_buffer(c2r_ctx *ctx, void *device_ptr, size_t count);
 int c2r_synchronize(c2r_ctx *ctx);
 
-/* Sources swept concurrently by one batch of launches (device scratch = 6 grids per source). */
+/* Most sources swept by one batch of launches (1..4096; default 256).  Their column blocks come out of a
+ * scratch arena (6 shell-ordered arrays per source, sized by the sub-boxes the source needed in the last
+ * pass); a batch is cut short when the arena cannot hold it. */
 int c2r_set_batch(c2r_ctx *ctx, int nbatch);
+
+/* ---- several GPUs: sources over ranks and the sum over ranks ----------------------------------------
+ * The reference's MPI strategy (master_slave.F90:74-96 do_grid_static, evolve.F90:505-548
+ * mpi_accumulate_grid_quantities): every rank holds the full grid, rank r sweeps sources r+1, r+1+npr, ...,
+ * six MPI_ALLREDUCE calls sum phih_grid, phihe_grid, phiheat, photon_loss and sum_nbox, every rank runs the
+ * global pass.  Here a rank is a GPU and the six sums are one fp64 ncclAllReduce (RCCL over xGMI) of the
+ * contiguous buffer above, device to device.
+ *
+ * One process per GPU (an MPI rank, a torch.distributed.run rank): c2r_create, then c2r_comm_init with the
+ * 128-byte id that ONE rank obtained from c2r_comm_unique_id and the launcher passed to the others (MPI_Bcast,
+ * a file, ...).  One process for several GPUs (the reference's no_mpi build): c2r_create_multi returns a
+ * context that applies every state-setting call to all its devices, runs passes on one host thread per device
+ * and reads results from the first; c2r_comm_init_local gives it its communicators (ncclCommInitAll).  The two
+ * compose: c2r_comm_init on a multi-device context makes its devices ranks first_rank, first_rank+1, ...
+ * RCCL is loaded on first use; single-GPU runs never touch it. */
+int c2r_device_count(void);
+int c2r_create_multi(c2r_ctx **out, int ndev, const int *devices, const int mesh[3]);
+int c2r_num_devices(const c2r_ctx *ctx);
+int c2r_comm_unique_id(char id[128]);
+int c2r_comm_init(c2r_ctx *ctx, int first_rank, int nranks, const char id[128]);
+int c2r_comm_init_local(c2r_ctx *ctx);
+int c2r_comm_destroy(c2r_ctx *ctx);
+int c2r_comm_rank(const c2r_ctx *ctx);
+int c2r_comm_nranks(const c2r_ctx *ctx);
+/* mpi_accumulate_grid_quantities (evolve.F90:505-548) after c2r_pass_sources: the whole buffer in one
+ * all-reduce; afterwards c2r_get_loss / c2r_download_rates return the summed photon_loss and sum_nbox_all.
+ * A no-op on a single rank without communicator.  On a multi-device context c2r_pass_sources(first, stride)
+ * gives device i the sources first + i*stride, first + i*stride + stride*ndev, ... */
+int c2r_allreduce_rates(c2r_ctx *ctx);
+/* One outer iteration's pass_all_sources + mpi_accumulate_grid_quantities + global_pass
+ * (evolve.F90:185-217) with all three overlapped: the rates launch of the last batch is cut into nslab slabs
+ * of k-planes, slab s is summed over the ranks while slab s+1 is computed, and its chemistry runs as soon as
+ * its sum is complete.  conv_flag: non-converged cells (evolve.F90:488). */
+int c2r_pass_allreduce_chemistry(c2r_ctx *ctx, int first, int stride, int nslab, double dt, int *conv_flag);
 
 /* Timing of the last c2r_pass_sources / c2r_global_pass on the context's stream, measured with
  * HIP events on that stream: milliseconds spent in the column sweep launches, the rates kernel

@@ -26,6 +26,23 @@ void pitch(const double *src, int ncol, std::vector<double> &dst) {
     dst[(size_t)c * NTAUP + NTAU + 1] = src[(size_t)c * (NTAU + 1) + NTAU];
   }
 }
+// what c2r_set_tables does on the host: tau_zero of every band of SED `sed` from its four tables
+void set_tau_zero(int sed, const std::vector<double> &pt, const std::vector<double> &pn, const std::vector<double> &ht,
+                  const std::vector<double> &hn) {
+  for (int b = 0; b < NFREQ; b++) {
+    const double *cols[8];
+    int n = 0;
+    cols[n++] = &pt[(size_t)b * NTAUP];
+    cols[n++] = &pn[(size_t)b * NTAUP];
+    const int nh = b < NB1 ? 1 : (b < NB1 + NB2 ? 2 : 3);
+    const int c0 = b < NB1 ? 0 : (b < NB1 + NB2 ? 2 * (b + 1) - NB1 - 2 : 3 * (b + 1) - NB2 - 2 * NB1 - 3);
+    for (int k = 0; k < nh; k++) {
+      cols[n++] = &ht[(size_t)(c0 + k) * NTAUP];
+      cols[n++] = &hn[(size_t)(c0 + k) * NTAUP];
+    }
+    T.bd.tau_zero[sed][b] = band_tau_zero(cols, n);
+  }
+}
 } // namespace
 
 extern "C" {
@@ -45,6 +62,9 @@ void hh_set_tables(const double *pthick, const double *pthin, const double *hthi
                      T.bd.f1heat_HI, T.bd.f1heat_HeI, T.bd.f1heat_HeII, T.bd.f2heat_HI, T.bd.f2heat_HeI, T.bd.f2heat_HeII};
   for (int i = 0; i < 12; i++) std::memcpy(dst[i], f[i], sizeof(double) * (NFREQ - 1));
   T.bd.bb_upper = bb_upper;
+  set_tau_zero(0, T.pthick, T.pthin, T.hthick, T.hthin);
+  for (int s = 1; s < 3; s++)
+    for (int b = 0; b < NFREQ; b++) T.bd.tau_zero[s][b] = (double)INFINITY;
   T.cool.assign(cool, cool + 5 * NCOOL);
   T.mintemp = mintemp;
   T.dtemp = dtemp;
@@ -84,6 +104,7 @@ void hh_set_sed(int sed, const double *pthick, const double *pthin, const double
   pitch(hthin, NHEAT, S_hn[k]);
   S_lo[k] = lower - 1;
   S_hi[k] = upper;
+  set_tau_zero(sed, S_pt[k], S_pn[k], S_ht[k], S_hn[k]);
 }
 static SedSet make_sedset() {
   SedSet ss;

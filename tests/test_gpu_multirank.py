@@ -94,3 +94,100 @@ def test_four_ranks_one_of_them_without_sources(pkg, gold):
         assert np.all(np.isfinite(r["phih"])) and np.all(r["phih"] >= 0)
     assert abs(res["loss"] / plain["loss"] - 1) < 1e-12
     assert abs(res["xh"][n:].mean() / plain["xh"][n:].mean() - 1) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The sum over ranks BEHIND the C ABI (c2r_comm_*, c2r_allreduce_rates, c2r_pass_allreduce_chemistry): no
+# torch.distributed anywhere near the data.
+
+def _engine(pkg, gold, devices, case="tap_N16_heat_3src.npz", call=2):
+    from test_host_logic import _inputs
+    i, o, mesh, mat, grid, src, cosmo = _inputs(pkg, gold, case, call)
+    e = pkg.HipEngine(mesh, devices)
+    e.set_tables(pkg.RadiationTables.load())
+    e.set_step(mat, grid, cosmo)
+    e.set_sources(src)
+    e.upload_state(mat)
+    return e, float(i["dt"][0]), src
+
+
+def _iterate(e, dt, niter, fused, first=1, stride=1):
+    e.begin_step()
+    conv = []
+    for _ in range(niter):
+        e.set_rates_to_zero()
+        if fused:
+            conv.append(e.pass_allreduce_chemistry(dt, first, stride, 3))
+        else:
+            e.pass_sources(first, stride)
+            e.allreduce_rates()
+            conv.append(e.global_pass(dt))
+    out = {**e.download_rates(), **e.download_iter_state()}
+    out["conv"] = conv
+    return out
+
+
+def test_rccl_single_rank_through_the_cabi(pkg, gold):
+    """c2r_comm_unique_id + c2r_comm_init (ncclCommInitRank, one rank) + the slab-pipelined iteration with its
+    ncclAllReduce calls: the sum over one rank changes nothing, so every grid equals the plain pass + global pass."""
+    e0, dt, _ = _engine(pkg, gold, 0)
+    ref = _iterate(e0, dt, 3, fused=False)          # no communicator: allreduce_rates is a no-op
+    e0.close()
+    e1, dt, _ = _engine(pkg, gold, 0)
+    e1.comm_init(0, 1, pkg.HipEngine.comm_unique_id())
+    assert e1.comm_size() == 1
+    got = _iterate(e1, dt, 3, fused=True)
+    e1.close()
+    e2, dt, _ = _engine(pkg, gold, 0)                # (a fresh engine: the passes have moved the temperatures)
+    e2.comm_init(0, 1, pkg.HipEngine.comm_unique_id())
+    got2 = _iterate(e2, dt, 3, fused=False)          # whole-buffer ncclAllReduce
+    e2.close()
+    for k, v in ref.items():
+        assert np.array_equal(np.asarray(v), np.asarray(got[k])), k
+        assert np.array_equal(np.asarray(v), np.asarray(got2[k])), k
+
+
+@pytest.mark.parametrize("nrep", [2, 4])
+def test_replicas_of_one_process_share_the_sources(pkg, gold, nrep):
+    """c2r_create_multi with the same device nrep times (the rehearsal mode of the one-process multi-GPU path:
+    RCCL refuses duplicate devices, so the replicas are summed in the process, in rank order): every replica
+    sweeps its share of the sources on its own host thread, the buffers are summed, the chemistry is replicated.
+    The sum must equal, bit for bit, the rank-ordered sum of single-engine passes over the same shares, and the
+    fused iteration must equal pass -> allreduce -> global pass."""
+    em, dt, src = _engine(pkg, gold, [0] * nrep)
+    em.comm_init_local()
+    assert em.num_devices() == nrep and em.comm_size() == nrep
+    em.begin_step()
+    em.set_rates_to_zero()
+    em.pass_sources(1, 1)
+    em.allreduce_rates()
+    got = em.download_rates()
+    # the same shares on single engines, summed in rank order on the host
+    acc = None
+    for r in range(nrep):
+        e, _, _ = _engine(pkg, gold, 0)
+        e.begin_step()
+        e.set_rates_to_zero()
+        e.pass_sources(1 + r, nrep)
+        d = e.download_rates()
+        e.close()
+        if acc is None:
+            acc = d
+        else:
+            for k in ("phih_grid", "phihe_grid", "phiheat", "photon_loss"):
+                acc[k] = acc[k] + d[k]
+            acc["sum_nbox"] += d["sum_nbox"]
+    for k in ("phih_grid", "phihe_grid", "phiheat", "photon_loss"):
+        assert np.array_equal(got[k], acc[k]), k
+    assert got["sum_nbox"] == acc["sum_nbox"]
+    em.close()
+    ea, dt, _ = _engine(pkg, gold, [0] * nrep)
+    ea.comm_init_local()
+    plain = _iterate(ea, dt, 3, fused=False)
+    ea.close()
+    eb, dt, _ = _engine(pkg, gold, [0] * nrep)
+    eb.comm_init_local()
+    fused = _iterate(eb, dt, 3, fused=True)
+    eb.close()
+    for k, v in plain.items():
+        assert np.array_equal(np.asarray(v), np.asarray(fused[k])), k
