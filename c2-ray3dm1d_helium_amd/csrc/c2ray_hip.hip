@@ -718,6 +718,48 @@ k_total_rates(size_t nc, RecCoef rc, double clumping_scalar, const float *__rest
   stat_block_reduce<3>(v, partial);
 }
 
+// minval(xh_av(:,:,:,0)), minval(xhe_av(:,:,:,0)) of the log line at evolve.F90:463-466 (a minimum is exact in any order)
+__global__ void __launch_bounds__(BLOCK)
+k_state_min(size_t nc, const double *__restrict__ xh, const double *__restrict__ xhe, double *__restrict__ partial) {
+  __shared__ double sh[2][BLOCK / 64];
+  double a = (double)INFINITY, b = (double)INFINITY;
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nc; q += (size_t)gridDim.x * BLOCK) {
+    a = dmin(a, xh[q]);
+    b = dmin(b, xhe[q]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a = dmin(a, __shfl_down(a, off, 64));
+    b = dmin(b, __shfl_down(b, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double r = sh[threadIdx.x][0];
+    for (int i = 1; i < BLOCK / 64; i++) r = dmin(r, sh[threadIdx.x][i]);
+    partial[(size_t)blockIdx.x * 2 + threadIdx.x] = r;
+  }
+}
+__global__ void __launch_bounds__(BLOCK)
+k_min_finish(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
+  __shared__ double sh[2][BLOCK / 64];
+  double a = (double)INFINITY, b = (double)INFINITY;
+  for (int i = threadIdx.x; i < nblocks; i += BLOCK) {
+    a = dmin(a, partial[(size_t)i * 2]);
+    b = dmin(b, partial[(size_t)i * 2 + 1]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a = dmin(a, __shfl_down(a, off, 64));
+    b = dmin(b, __shfl_down(b, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double r = sh[threadIdx.x][0];
+    for (int i = 1; i < BLOCK / 64; i++) r = dmin(r, sh[threadIdx.x][i]);
+    out[threadIdx.x] = r;
+  }
+}
+
 template <int NV>
 __global__ void __launch_bounds__(BLOCK)
 k_stat_finish(const double *__restrict__ partial, int nblocks, double *__restrict__ out) {
@@ -2370,6 +2412,33 @@ extern "C" int c2r_fraction_means(c2r_ctx *c, int which, double out5[5]) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int n = 0; n < 5; n++) out5[n] = c->h_stat[n] / (double)c->g.ncell;
   return 0;
+}
+
+extern "C" int c2r_fraction_minima(c2r_ctx *c, int which, double out2[2]) {
+  if (!c || !out2) return 1;
+  if (!c->have_state) return fail(c, "c2r_fraction_minima: state not set");
+  if (which < 0 || which > 2) return fail(c, "c2r_fraction_minima: which = %d not in {0,1,2}", which);
+  HIPCHK(c, hipSetDevice(c->device));
+  const double *xh = which == 0 ? c->d_xh : (which == 1 ? c->d_xh_int : c->d_xh_av);
+  const double *xhe = which == 0 ? c->d_xhe : (which == 1 ? c->d_xhe_int : c->d_xhe_av);
+  hipLaunchKernelGGL(k_state_min, dim3(STAT_BLOCKS), dim3(BLOCK), 0, c->stream, c->g.ncell, xh, xhe, c->d_stat);
+  hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(BLOCK), 0, c->stream, c->d_stat, STAT_BLOCKS, c->d_stat + STAT_BLOCKS * 5);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_stat, c->d_stat + STAT_BLOCKS * 5, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out2[0] = c->h_stat[0];
+  out2[1] = c->h_stat[1];
+  return 0;
+}
+
+// The numerical and algorithmic parameters compiled into the device code, in the order of the header's list.
+extern "C" int c2r_get_constants(double *out, int capacity) {
+  const double v[] = {(double)SUBBOXSIZE, (double)MAX_SUBBOX, abu_he, abu_c, epsilon, convergence_fraction,
+                      minimum_fractional_change, minimum_fraction_of_atoms, relative_denergy, minitemp,
+                      (double)NTAU, minlogtau, 4.0 /* maxlogtau */, (double)NFREQ, (double)NHEAT};
+  const int n = (int)(sizeof v / sizeof v[0]);
+  for (int i = 0; i < n && i < capacity; i++) out[i] = v[i];
+  return n;
 }
 
 extern "C" int c2r_total_rates(c2r_ctx *c, double dt, const double reccoef[12], double out3[3]) {

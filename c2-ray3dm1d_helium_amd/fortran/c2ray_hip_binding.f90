@@ -287,6 +287,78 @@ module c2ray_hip
        real(c_double), intent(out) :: out5(5)
      end function c2r_fraction_means
 
+     integer(c_int) function c2r_fraction_minima(ctx, which, out2) bind(C, name="c2r_fraction_minima")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which
+       real(c_double), intent(out) :: out2(2)
+     end function c2r_fraction_minima
+
+     integer(c_int) function c2r_get_constants(out, capacity) bind(C, name="c2r_get_constants")
+       import :: c_int, c_double
+       real(c_double), intent(out) :: out(*)
+       integer(c_int), value :: capacity
+     end function c2r_get_constants
+
+     ! ---- several GPUs: sources over ranks and the sum over ranks (RCCL inside the library) ----
+     integer(c_int) function c2r_device_count() bind(C, name="c2r_device_count")
+       import :: c_int
+     end function c2r_device_count
+
+     integer(c_int) function c2r_create_multi(ctx, ndev, devices, mesh) bind(C, name="c2r_create_multi")
+       import :: c_int, c_ptr
+       type(c_ptr), intent(out) :: ctx
+       integer(c_int), value :: ndev
+       integer(c_int), intent(in) :: devices(*)
+       integer(c_int), intent(in) :: mesh(3)
+     end function c2r_create_multi
+
+     integer(c_int) function c2r_num_devices(ctx) bind(C, name="c2r_num_devices")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_num_devices
+
+     integer(c_int) function c2r_comm_unique_id(id) bind(C, name="c2r_comm_unique_id")
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id(128)
+     end function c2r_comm_unique_id
+
+     integer(c_int) function c2r_comm_init(ctx, first_rank, nranks, id) bind(C, name="c2r_comm_init")
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: first_rank, nranks
+       character(kind=c_char), intent(in) :: id(128)
+     end function c2r_comm_init
+
+     integer(c_int) function c2r_comm_init_local(ctx) bind(C, name="c2r_comm_init_local")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_comm_init_local
+
+     integer(c_int) function c2r_comm_destroy(ctx) bind(C, name="c2r_comm_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_comm_destroy
+
+     integer(c_int) function c2r_comm_nranks(ctx) bind(C, name="c2r_comm_nranks")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_comm_nranks
+
+     integer(c_int) function c2r_allreduce_rates(ctx) bind(C, name="c2r_allreduce_rates")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_allreduce_rates
+
+     integer(c_int) function c2r_pass_allreduce_chemistry(ctx, first, stride, nslab, dt, conv_flag) &
+          bind(C, name="c2r_pass_allreduce_chemistry")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: first, stride, nslab
+       real(c_double), value :: dt
+       integer(c_int), intent(out) :: conv_flag
+     end function c2r_pass_allreduce_chemistry
+
      integer(c_int) function c2r_total_rates(ctx, dt, reccoef, out3) bind(C, name="c2r_total_rates")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

@@ -266,21 +266,14 @@ contains
     call check (c2r_pass_sources (hip_ctx, int(1+rank,c_int), int(npr,c_int)), "c2r_pass_sources")
 #endif
 
-#ifdef MPI
-    ! mpi_accumulate_grid_quantities (evolve.F90:505-548) through host staging buffers
-    call download_rates ()
-    call mpi_sum_in_place (phih_grid, size(phih_grid))
-    call mpi_sum_in_place (phihe_grid, size(phihe_grid))
-    if (.not.isothermal) call mpi_sum_in_place (phiheat, size(phiheat))
-    call mpi_sum_in_place (photon_loss_all, NumFreqBnd)
-    call MPI_ALLREDUCE (sum_nbox, sum_nbox_all, 1, MPI_INTEGER, MPI_SUM, MPI_COMM_NEW, mympierror)
-    call check (c2r_upload_rates (hip_ctx, phih_grid, phihe_grid, phiheat), "c2r_upload_rates")
-#else
+    ! mpi_accumulate_grid_quantities (evolve.F90:505-548): one RCCL all-reduce of the rate grids, photon_loss
+    ! and sum_nbox, device to device, over the GPUs of all ranks (nothing to do for one GPU); afterwards
+    ! c2r_get_loss returns the sums
+    call check (c2r_allreduce_rates (hip_ctx), "c2r_allreduce_rates")
     call check (c2r_get_loss (hip_ctx, tail, nbox), "c2r_get_loss")
     photon_loss_all(:)=tail(:)
     sum_nbox=nbox
     sum_nbox_all=nbox
-#endif
 
   end subroutine pass_all_sources
 
@@ -293,10 +286,17 @@ contains
     real(kind=dp),intent(in) :: dt
 
     integer(c_int) :: cf
-    real(kind=dp) :: means(5), n_now(5)
+    real(kind=dp) :: means(5), n_now(5), minima(2)
 
     ! mean photon loss per cell (evolve.F90:457)
     photon_loss(:)=photon_loss_all(:)/(real(mesh(1))*real(mesh(2))*real(mesh(3)))
+
+    ! Report minimum value of xh_av(0) to check for zeros (evolve.F90:463-466)
+    if (rank == 0) then
+       call check (c2r_fraction_minima (hip_ctx, 2_c_int, minima), "c2r_fraction_minima")
+       write(logf,*) "min xh_av: ",minima(1)
+       write(logf,*) "min xhe_av: ",minima(2)
+    endif
 
     if (rank == 0) write(logf,*) 'Doing global '
     call check (c2r_global_pass (hip_ctx, dt, cf), "c2r_global_pass")
@@ -355,9 +355,7 @@ contains
     call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
          "c2r_download_rates")
     sum_nbox=nbox
-#ifndef MPI
     sum_nbox_all=nbox
-#endif
 
   end subroutine download_rates
 
@@ -676,17 +674,6 @@ contains
 
   ! ===========================================================================
 
-#ifdef MPI
-  subroutine mpi_sum_in_place (a, n)
-    integer,intent(in) :: n
-    real(kind=dp),intent(inout) :: a(n)
-    real(kind=dp),allocatable :: buffer(:)
-    allocate(buffer(n))
-    call MPI_ALLREDUCE (a, buffer, n, MPI_DOUBLE_PRECISION, MPI_SUM, MPI_COMM_NEW, mympierror)
-    a(:)=buffer(:)
-    deallocate(buffer)
-  end subroutine mpi_sum_in_place
-#endif
 
   ! ===========================================================================
 
@@ -701,6 +688,10 @@ contains
        write(logf,*) "c2ray_hip: ", what, " failed: ", c2r_error_text (hip_ctx)
        write(*,*) "c2ray_hip: ", what, " failed: ", c2r_error_text (hip_ctx)
        flush(logf)
+#ifdef MPI
+       ! the other ranks would wait in their next collective for ever
+       call MPI_ABORT (MPI_COMM_NEW, 1, mympierror)
+#endif
        stop 1
     endif
 

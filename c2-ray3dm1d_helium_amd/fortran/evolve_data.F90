@@ -6,13 +6,18 @@
 !! them); coldensh_out etc. are scratch of the reference's CPU sweep and have no host mirror.
 module evolve_data
 
-  use, intrinsic :: iso_c_binding, only: c_ptr, c_null_ptr, c_int
-  use c2ray_hip, only: c2r_create, c2r_error_text
+  use, intrinsic :: iso_c_binding, only: c_ptr, c_null_ptr, c_int, c_char, c_double
+  use c2ray_hip, only: c2r_create, c2r_create_multi, c2r_error_text, c2r_device_count, c2r_get_constants
+  use c2ray_hip, only: c2r_comm_unique_id, c2r_comm_init, c2r_comm_init_local
   use file_admin, only: logf
-  use my_mpi                                  ! rank
+  use my_mpi                                  ! rank, npr, MPI_COMM_NEW
   use precision, only: dp
-  use radiation_sizes, only: NumFreqBnd
+  use radiation_sizes, only: NumFreqBnd, NumheatBin, NumTau
   use sizes, only: Ndim, mesh
+  use abundances, only: abu_he, abu_c
+  use c2ray_parameters, only: subboxsize, max_subbox, epsilon, convergence_fraction
+  use c2ray_parameters, only: minimum_fractional_change, minimum_fraction_of_atoms
+  use c2ray_parameters, only: relative_denergy, minitemp, add_photon_losses
 
   implicit none
   save
@@ -32,10 +37,11 @@ module evolve_data
   !> photons that left the mesh, per frequency band, summed over sources (and ranks)
   real(kind=dp) :: photon_loss_all(NumFreqBnd)
 
-  !> The device context (include/c2ray_hip.h); one per rank = one per GPU
+  !> The device context (include/c2ray_hip.h): the GPU(s) of this rank
   type(c_ptr) :: hip_ctx = c_null_ptr
-  !> GPU used by this rank
+  !> first GPU used by this rank, and how many it drives (C2RAY_HIP_NGPU > 1: one process, several GPUs)
   integer :: hip_device = 0
+  integer :: hip_ndevices = 1
 
 contains
 
@@ -45,9 +51,10 @@ contains
 
     integer(c_int) :: ierr
     integer(c_int) :: cmesh(3)
-    character(len=16) :: value
+    integer(c_int), allocatable :: devices(:)
+    character(len=32) :: value
     integer :: length, status
-    integer :: n1, n2, n3
+    integer :: n1, n2, n3, ndev_node, local_rank, offset, i
 
     n1 = mesh(1)
     n2 = mesh(2)
@@ -61,20 +68,144 @@ contains
     allocate(xhe_av(n1,n2,n3,0:2), xhe_intermed(n1,n2,n3,0:2))
     photon_loss_all(:) = 0.0_dp
 
-    ! one rank per GPU: rank r of a node uses device r unless C2RAY_HIP_DEVICE says otherwise
-    hip_device = rank
-    call get_environment_variable("C2RAY_HIP_DEVICE", value, length, status)
-    if (status == 0 .and. length > 0) read(value(1:length),*) hip_device
+    call check_compiled_constants ()
+
+    ! Which GPU(s).  A rank drives C2RAY_HIP_NGPU devices (default 1) starting at
+    ! (node-local rank * C2RAY_HIP_NGPU + C2RAY_HIP_DEVICE) modulo the devices of the node; the node-local
+    ! rank is what the MPI launcher exports (Open MPI, MVAPICH, Slurm), else the global rank.
+    ndev_node = c2r_device_count ()
+    local_rank = rank
+    call env_integer ("OMPI_COMM_WORLD_LOCAL_RANK", local_rank)
+    call env_integer ("MV2_COMM_WORLD_LOCAL_RANK", local_rank)
+    call env_integer ("SLURM_LOCALID", local_rank)
+    offset = 0
+    call env_integer ("C2RAY_HIP_DEVICE", offset)
+    hip_ndevices = 1
+    call env_integer ("C2RAY_HIP_NGPU", hip_ndevices)
+    hip_ndevices = max(1, hip_ndevices)
+    allocate(devices(hip_ndevices))
+    do i = 1, hip_ndevices
+       devices(i) = int(modulo(local_rank*hip_ndevices + offset + i - 1, max(1, ndev_node)), c_int)
+    enddo
+    ! C2RAY_HIP_SAME_DEVICE=1: all on one GPU (a rehearsal of the multi-device path on a one-GPU box)
+    i = 0
+    call env_integer ("C2RAY_HIP_SAME_DEVICE", i)
+    if (i /= 0) devices(:) = int(modulo(offset, max(1, ndev_node)), c_int)
+    hip_device = devices(1)
 
     cmesh(:) = mesh(:)
-    ierr = c2r_create(hip_ctx, int(hip_device, c_int), cmesh)
-    if (ierr /= 0) then
-       write(logf,*) "c2ray_hip: ", c2r_error_text(c_null_ptr)
-       write(*,*) "c2ray_hip: ", c2r_error_text(c_null_ptr)
-       stop 1
+    if (hip_ndevices > 1) then
+       ierr = c2r_create_multi(hip_ctx, int(hip_ndevices, c_int), devices, cmesh)
+    else
+       ierr = c2r_create(hip_ctx, devices(1), cmesh)
     endif
-    if (rank == 0) write(logf,"(A,I3)") "evolve_ini: evolve3D runs on HIP device ", hip_device
+    if (ierr /= 0) call stop_with (c2r_error_text(c_null_ptr))
+    if (rank == 0) write(logf,"(A,I3,A,I3)") "evolve_ini: evolve3D runs on HIP device ", hip_device, &
+         ", devices per rank: ", hip_ndevices
+
+    call setup_communicator ()
 
   end subroutine evolve_ini
+
+  !> The sum over ranks of mpi_accumulate_grid_quantities (files_for_3D/evolve.F90:505-548) is an RCCL
+  !! all-reduce inside the library.  All it needs from the host's own parallel layer is to carry 128 bytes from
+  !! rank 0 to the others once.
+  subroutine setup_communicator ()
+
+    character(kind=c_char) :: id(128)
+    integer(c_int) :: ierr
+    integer :: force
+#ifdef MPI
+    integer :: mympierror
+#endif
+
+    if (npr > 1) then
+#ifdef MPI
+       if (rank == 0) then
+          ierr = c2r_comm_unique_id (id)
+          if (ierr /= 0) call stop_with (c2r_error_text(c_null_ptr))
+       endif
+       call MPI_BCAST (id, 128, MPI_CHARACTER, 0, MPI_COMM_NEW, mympierror)
+       ierr = c2r_comm_init (hip_ctx, int(rank*hip_ndevices, c_int), int(npr*hip_ndevices, c_int), id)
+       if (ierr /= 0) call stop_with (c2r_error_text(hip_ctx))
+#else
+       call stop_with ("npr > 1 in a build without MPI")
+#endif
+    elseif (hip_ndevices > 1) then
+       ierr = c2r_comm_init_local (hip_ctx)
+       if (ierr /= 0) call stop_with (c2r_error_text(hip_ctx))
+    else
+       ! C2RAY_HIP_FORCE_COMM=1: a communicator of one rank, so that a one-GPU run goes through the very calls
+       ! (ncclCommInitRank, ncclAllReduce) a multi-rank run makes
+       force = 0
+       call env_integer ("C2RAY_HIP_FORCE_COMM", force)
+       if (force /= 0) then
+          ierr = c2r_comm_unique_id (id)
+          if (ierr /= 0) call stop_with (c2r_error_text(c_null_ptr))
+          ierr = c2r_comm_init (hip_ctx, 0_c_int, 1_c_int, id)
+          if (ierr /= 0) call stop_with (c2r_error_text(hip_ctx))
+          if (rank == 0) write(logf,*) "evolve_ini: RCCL communicator of one rank (C2RAY_HIP_FORCE_COMM)"
+       endif
+    endif
+
+  end subroutine setup_communicator
+
+  !> The device code has the numerical parameters of the reference compiled in (c2r_get_constants); a host
+  !! built with other values in c2ray_parameters.f90 / abundances.f90 / radiation_sizes.f90 must not run.
+  subroutine check_compiled_constants ()
+
+    real(c_double) :: c(32)
+    real(kind=dp) :: host(15)
+    character(len=28), parameter :: names(15) = (/ "subboxsize                  ", &
+         "max_subbox                  ", "abu_he                      ", "abu_c                       ", &
+         "epsilon                     ", "convergence_fraction        ", "minimum_fractional_change   ", &
+         "minimum_fraction_of_atoms   ", "relative_denergy            ", "minitemp                    ", &
+         "NumTau                      ", "minlogtau                   ", "maxlogtau                   ", &
+         "NumFreqBnd                  ", "NumheatBin                  " /)
+    integer :: n, i
+
+    n = c2r_get_constants (c, 32_c_int)
+    host = (/ real(subboxsize,dp), real(max_subbox,dp), real(abu_he,dp), real(abu_c,dp), real(epsilon,dp), &
+         real(convergence_fraction,dp), real(minimum_fractional_change,dp), real(minimum_fraction_of_atoms,dp), &
+         real(relative_denergy,dp), real(minitemp,dp), real(NumTau,dp), -20.0_dp, 4.0_dp, &
+         real(NumFreqBnd,dp), real(NumheatBin,dp) /)
+    do i = 1, min(n, 15)
+       if (c(i) /= host(i)) then
+          write(logf,*) "c2ray_hip: ", trim(names(i)), " of this build is ", host(i), &
+               " but the device library was compiled with ", c(i)
+          call stop_with ("parameter "//trim(names(i))//" differs from the value compiled into libc2ray_hip")
+       endif
+    enddo
+    if (add_photon_losses) call stop_with ("add_photon_losses = .true. (distribute_photon_losses, "// &
+         "evolve_point.F90:546) is not implemented on the device")
+
+  end subroutine check_compiled_constants
+
+  subroutine env_integer (name, value)
+    character(len=*), intent(in) :: name
+    integer, intent(inout) :: value
+    character(len=32) :: text
+    integer :: length, status, v, ios
+    call get_environment_variable(name, text, length, status)
+    if (status == 0 .and. length > 0) then
+       read(text(1:length),*,iostat=ios) v
+       if (ios == 0) value = v
+    endif
+  end subroutine env_integer
+
+  !> log the text and end the run on every rank
+  subroutine stop_with (text)
+    character(len=*), intent(in) :: text
+#ifdef MPI
+    integer :: mympierror
+#endif
+    write(logf,*) "c2ray_hip: ", text
+    write(*,*) "c2ray_hip: ", text
+    flush(logf)
+#ifdef MPI
+    call MPI_ABORT (MPI_COMM_NEW, 1, mympierror)
+#endif
+    stop 1
+  end subroutine stop_with
 
 end module evolve_data

@@ -213,6 +213,18 @@ void *c2r_rates_device_ptr(c2r_ctx *ctx);
 int c2r_set_rates_buffer(c2r_ctx *ctx, void *device_ptr, size_t count);
 int c2r_synchronize(c2r_ctx *ctx);
 
+/* minval(xh(:,:,:,0)), minval(xhe(:,:,:,0)) of the grids `which` selects as in c2r_fraction_means: the
+ * "min xh_av / min xhe_av" log lines of global_pass (evolve.F90:463-466) want which = 2. */
+int c2r_fraction_minima(c2r_ctx *ctx, int which, double out2[2]);
+
+/* The numerical and algorithmic parameters that are COMPILED INTO the device code, for a host to compare with
+ * the modules it was built with (c2ray_parameters.f90, abundances.f90, radiation_sizes.f90) before the first
+ * step -- linking, say, c2ray_parameters_TEST4.f90 (subboxsize = mesh(1)) must stop the run, not silently
+ * trace other sub-boxes.  out[0..]: subboxsize, max_subbox, abu_he, abu_c, epsilon, convergence_fraction,
+ * minimum_fractional_change, minimum_fraction_of_atoms, relative_denergy, minitemp, NumTau, minlogtau,
+ * maxlogtau, NumFreqBnd, NumheatBin.  Returns how many there are (15). */
+int c2r_get_constants(double *out, int capacity);
+
 /* Most sources swept by one batch of launches (1..4096; default 256).  Their column blocks come out of a
  * scratch arena (6 shell-ordered arrays per source, sized by the sub-boxes the source needed in the last
  * pass); a batch is cut short when the arena cannot hold it. */

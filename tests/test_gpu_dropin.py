@@ -28,6 +28,13 @@ sys.path.insert(0, str(ROOT / "oracle"))
     # (c2r_build_tables) instead of uploading rad_ini's host arrays
     (False, "devtables", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     (True, False, [(8, 8, 8, 1e55)]),
+    # C2RAY_HIP_FORCE_COMM=1: the shim creates a one-rank RCCL communicator (c2r_comm_unique_id, c2r_comm_init)
+    # and every iteration's c2r_allreduce_rates is a real ncclAllReduce
+    (False, "comm1", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
+    # C2RAY_HIP_NGPU=2 on one GPU (C2RAY_HIP_SAME_DEVICE=1): c2r_create_multi, one host thread per replica, each
+    # sweeping one of the two sources, the in-process sum over the replicas, replicated chemistry.  Two sources
+    # over two ranks add up as (0 + s1) + s2 either way: still byte-identical files
+    (False, "ngpu2", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
     # the -DPL -DQUASARS build (the flags of the reference's production targets, Makefile:185-186,207-208)
     (False, True, [(8, 8, 8, 1e55, 3e54, 0.0), (2, 15, 4, 0.0, 2e54, 4e54), (16, 1, 9, 2e54, 0.0, 1e54)]),
 ])
@@ -36,12 +43,18 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     if pl == "devtables":
         monkeypatch.setenv("C2RAY_HIP_BUILD_TABLES", "1")
     devtables = pl == "devtables"
+    if pl == "comm1":
+        monkeypatch.setenv("C2RAY_HIP_FORCE_COMM", "1")
+    if pl == "ngpu2":
+        monkeypatch.setenv("C2RAY_HIP_NGPU", "2")
+        monkeypatch.setenv("C2RAY_HIP_SAME_DEVICE", "1")
+    comm1, ngpu2 = pl == "comm1", pl == "ngpu2"
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
     which_hip = "hip_dogrid" if dogrid else "hip"
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "")
     r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl, lls=lls)
     r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls)
     files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
@@ -50,8 +63,17 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), f
     # same iteration history in the log
     assert refrun.parse_log(r1) == refrun.parse_log(r2)
+    log2 = (r2 / "results" / "C2Ray.log").read_text(errors="replace")
     if devtables:
-        assert "tables built on the device for SED  0" in (r2 / "results" / "C2Ray.log").read_text(errors="replace")
+        assert "tables built on the device for SED  0" in log2
+    if comm1:
+        assert "RCCL communicator of one rank" in log2
+    if ngpu2:
+        assert "devices per rank:   2" in log2
+    # the reference's "min xh_av" / "min xhe_av" lines (evolve.F90:463-466), from a device minimum: same numbers
+    import re
+    mins = lambda run: re.findall(r"min xhe?_av:\s+(\S+)", (run / "results" / "C2Ray.log").read_text(errors="replace"))
+    assert len(mins(r1)) > 0 and mins(r1) == mins(r2)
     # photon statistics (written from host arrays the HIP path filled): compare the numbers
     a = (r1 / "results" / "PhotonCounts2.out").read_text().split()
     b = (r2 / "results" / "PhotonCounts2.out").read_text().split()
