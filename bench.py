@@ -6,11 +6,16 @@ A "step" is ONE outer iteration of evolve3D (files_for_3D/evolve.F90:185-217): s
 pass_all_sources (column sweep + rates for every source of this rank), the sum of the rate grids over
 ranks when N > 1, and the global chemistry pass.  Inputs are resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload config3|config4]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank sweeps --sources sources
-(weak scaling: per-GPU work fixed), the rate grids are all-reduced over RCCL, chemistry is replicated
-as in the reference.  value = mesh^3 x (sources x N) x K / max-over-ranks time.
+N > 1: launched by torch.distributed.run, one rank per GPU.  The sum over ranks is an RCCL all-reduce INSIDE
+the library (c2r_comm_init / c2r_pass_allreduce_chemistry, include/c2ray_hip.h); torch.distributed (gloo) only
+carries the 128-byte RCCL id to the ranks and does the barrier / max-over-ranks of this harness.
+
+  --workload config3 (default; BASELINE configs[2]): every rank sweeps --sources sources of its own (weak
+      scaling: per-GPU work fixed); value = mesh^3 x (sources x N) x K / max-over-ranks time.
+  --workload config4 (BASELINE configs[3]): 1024 seeded sources over a log-normal 256^3 box, neutral start,
+      dealt to the ranks as do_grid_static does (1+rank, NumSrc, N): strong scaling, the north star's 2/4/8 case.
 """
 from __future__ import annotations
 
@@ -27,36 +32,37 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
-SWEEP_BYTES_PER_CELL_SOURCE = 136.0   # SURVEY.md section 8(d), isothermal sweep (evolve0D)
+# SURVEY.md section 8(d), per cell.source of evolve0D (= column sweep + rates here), isothermal
+EVOLVE0D_BYTES = 136.0                # one source at a time: 40 state + 48 columns + 48 rate read-modify-write
 COLUMN_BYTES_PER_CELL_SOURCE = 88.0   # column sweep alone: 40 B state + 48 B columns
 CHEM_BYTES_PER_CELL = 252.0           # SURVEY.md section 8(d), isothermal chemistry pass
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = ROOT / "profiles" / "r01_bench_pmc_summary.json"
+PMC_SUMMARY = ROOT / "profiles" / "r02_bench_pmc_summary.json"
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes of this same command (tools/pmc_summary.py; FETCH_SIZE doubled as the guide's gfx950
-    correction prescribes), or None."""
+def rates_bytes_per_launch(cells, nsrc, heating=False):
+    """Compulsory HBM bytes of one k_rates launch over `nsrc` sources: the six columns of every cell.source,
+    and per cell the state (40 B) and the rate grids read and written once (3 or 4 grids)."""
+    return cells * (nsrc * 48.0 + 40.0 + (64.0 if heating else 48.0))
+
+
+def stored_counter(kernel, counter):
+    """A per-launch counter of the committed rocprofv3 --pmc passes of this same command (tools/pmc_summary.py),
+    or None.  Stored, not measured in this run: the keys that use it say so."""
     try:
-        return json.loads(PMC_SUMMARY.read_text())[kernel]["hbm_bytes_per_launch_corrected"]
+        v = json.loads(PMC_SUMMARY.read_text())[kernel][counter]
+        return v["per_launch"] if isinstance(v, dict) else v
     except Exception:
         return None
 
 
-def measured_counter(kernel, counter):
-    try:
-        return json.loads(PMC_SUMMARY.read_text())[kernel][counter]["per_launch"]
-    except Exception:
-        return None
-
-
-def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False):
+def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False, neutral=False):
     """Synthetic inputs of BASELINE configs[2]: uniform density of the
     reference's test problem at z = 9, isothermal 1e4 K, sources at seeded positions
     (numpy default_rng(12345), integers in [1, n]) of 1e56 photons/s each.  The gas starts highly
     ionised (x_HI ~ 1e-3) so that every source's sub-boxes run to the full box: swept cells ==
-    mesh^3 per source, the regime the metric is defined on."""
+    mesh^3 per source, the regime the metric is defined on.  neutral=True: the reference's test-problem start
+    (x_HI = 1 - 1e-20) instead -- small sub-boxes, chemistry in its expensive state."""
     hp = pkg.hostphys
     zred = 9.0
     dr, vol = hp.test_grid(n, zred)
@@ -65,9 +71,14 @@ def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False
     allpos = rng.integers(1, n + 1, size=(first_source + nsrc, 3)).astype(np.int32)
     srcpos = allpos[first_source:]
     ndens = np.full(nc, hp.test_density(zred))
-    x0 = 1.0e-3 * (1.0 + 0.5 * np.sin(np.arange(nc, dtype=np.float64) * 1.0e-3))  # neutral fraction
-    xh = np.concatenate([x0, 1.0 - x0])
-    xhe = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
+    if neutral:
+        eps = 1.0e-20
+        xh = np.concatenate([np.full(nc, 1.0 - eps), np.full(nc, eps)])
+        xhe = np.concatenate([np.full(nc, 1.0 - 2 * eps), np.full(nc, eps), np.full(nc, eps)])
+    else:
+        x0 = 1.0e-3 * (1.0 + 0.5 * np.sin(np.arange(nc, dtype=np.float64) * 1.0e-3))  # neutral fraction
+        xh = np.concatenate([x0, 1.0 - x0])
+        xhe = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
     temp = np.full(3 * nc, 1.0e4, dtype=np.float32) if heating else None
     mat = pkg.Material(ndens, xh, xhe, temp, not heating, 1.0e4, 1.0, hp.reccoef(1.0e4))
     grid = pkg.GridProps((n, n, n), dr, vol)
@@ -76,9 +87,32 @@ def config3_inputs(pkg, n=256, nsrc=8, seed=12345, first_source=0, heating=False
     return mat, grid, src, cosmo
 
 
-def cpu_baseline(pkg, mesh=160, nsrc=8):
-    """The oracle (C port of the reference's path, bit-identical to it) on a bounded sample of the same
-    workload, on ALL host cores: one outer iteration on a mesh^3 box with nsrc sources, the sweep in
+def config4_inputs(pkg, n=256, nsrc=1024, seed=2024, heating=False):
+    """BASELINE configs[3]: log-normal density (sigma_ln = 1, seed 2024, mean of the test
+    problem at z = 9), 1024 seeded sources with log-uniform luminosities 1e52..1e54 photons/s, neutral start."""
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    rng = np.random.default_rng(seed)
+    ln = rng.normal(0.0, 1.0, nc)
+    ndens = hp.test_density(zred) * np.exp(ln - 0.5)          # mean-preserving log-normal
+    srcpos = rng.integers(1, n + 1, size=(nsrc, 3)).astype(np.int32)
+    flux = 10.0 ** rng.uniform(52.0, 54.0, nsrc) / 1.0e48
+    eps = 1.0e-20
+    xh = np.concatenate([np.full(nc, 1.0 - eps), np.full(nc, eps)])
+    xhe = np.concatenate([np.full(nc, 1.0 - 2 * eps), np.full(nc, eps), np.full(nc, eps)])
+    temp = np.full(3 * nc, 1.0e4, dtype=np.float32) if heating else None
+    mat = pkg.Material(ndens, xh, xhe, temp, not heating, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, flux, 1.0e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    return mat, grid, src, cosmo
+
+
+def cpu_baseline(pkg, mesh=256, nsrc=8):
+    """The oracle (C port of the reference's path, bit-identical to it on the golden fixtures) on ONE STEP OF THIS
+    VERY WORKLOAD -- 256^3, 8 sources, the same seeded inputs --, on the host cores of one GPU's share: the sweep in
     L-infinity shell order with the cells of a shell over OpenMP threads (columns and rates equal the serial
     sweep's bit for bit, tests/test_oracle_golden.py), the global pass cell-parallel.  Reported, not a target."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -97,8 +131,8 @@ def cpu_baseline(pkg, mesh=160, nsrc=8):
     orc.global_pass_threads(T, st, s, 1.0e7 * pkg.hostphys.YEAR, threads)
     dt = time.perf_counter() - t0
     return {"value": mesh ** 3 * nsrc / dt, "unit": "cell-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{mesh}^3 box, {nsrc} sources, 1 outer iteration (shell-parallel sweep + chemistry) on {threads} "
-                      f"OpenMP threads, {dt:.1f} s wall"}
+            "sample": f"one step of this workload ({mesh}^3 box, {nsrc} sources, same seeded inputs): shell-parallel sweep + "
+                      f"cell-parallel chemistry of the oracle on {threads} OpenMP threads, {dt:.1f} s wall"}
 
 
 def cpu_baseline_reference(mesh=64):
@@ -132,21 +166,24 @@ def cpu_baseline_reference(mesh=64):
     if niter == 0 or total <= 0:
         return None
     return {"value": mesh ** 3 * niter / total, "unit": "cell-updates/s", "cores": threads, "kind": "reference",
-            "sample": f"reference binary (flang -O2{', OpenMP' if omp else ', serial'}), {mesh}^3 box, 1 source, isothermal, {niter} outer "
-                      f"iterations of evolve3D in {total:.1f} s (nominal mesh^3 x sources per iteration, as the metric)"}
+            "sample": f"reference binary (flang -O2{', OpenMP' if omp else ', serial'}), its own test problem: {mesh}^3 box, 1 source, "
+                      f"isothermal, {niter} outer iterations of evolve3D in {total:.1f} s (nominal mesh^3 x sources per iteration, as the metric)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["config3", "config4"], default="config3")
     ap.add_argument("--mesh", type=int, default=256)
-    ap.add_argument("--sources", type=int, default=8, help="sources per GPU")
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--sources", type=int, default=None, help="config3: sources per GPU (default 8); config4: total (default 1024)")
+    ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--heating", action="store_true",
                     help="non-isothermal variant (heating tables, thermal evolution); not the headline config")
+    ap.add_argument("--neutral-start", action="store_true",
+                    help="config3 from the reference's neutral test-problem start (small sub-boxes, chemistry in its expensive state)")
     a = ap.parse_args()
 
     import torch
@@ -158,33 +195,44 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
-    comm = None
-    if world > 1 or os.environ.get("C2R_BENCH_FORCE_COMM"):   # the env knob rehearses the N > 1 code path on one GPU
+    dist = None
+    force_comm = bool(os.environ.get("C2R_BENCH_FORCE_COMM"))   # rehearses the N > 1 code path (RCCL, one rank) on one GPU
+    if world > 1 or force_comm:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        comm = pkg.parallel.TorchComm()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # plumbing only: the id of the library's RCCL communicator, the barrier and the max over ranks below
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n = a.mesh
-    total_src = a.sources * world
-    # every rank holds the full source list; rank r sweeps r+1, r+1+world, ... (master_slave.F90:85)
-    mat, grid, src, cosmo = config3_inputs(pkg, n, total_src, heating=a.heating)
+    cfg4 = a.workload == "config4"
+    if cfg4:
+        total_src = a.sources or 1024
+        per_gpu = len(range(rank, total_src, world))
+        mat, grid, src, cosmo = config4_inputs(pkg, n, total_src, heating=a.heating)
+        batch = a.batch or 256
+    else:
+        per_gpu = a.sources or 8
+        total_src = per_gpu * world
+        # every rank holds the full source list; rank r sweeps r+1, r+1+world, ... (master_slave.F90:85)
+        mat, grid, src, cosmo = config3_inputs(pkg, n, total_src, heating=a.heating, neutral=a.neutral_start)
+        batch = a.batch or 8
     tables = pkg.RadiationTables.load()
     e = pkg.HipEngine((n, n, n), local)
     e.set_tables(tables)
     e.set_step(mat, grid, cosmo)
     e.set_sources(src)
     e.upload_state(mat)
-    e.set_batch(a.batch)
+    e.set_batch(batch)
     e.enable_timing(True)
-    if comm is not None:
-        e.use_torch_rates_buffer(f"cuda:{local}")
+    comm = pkg.parallel.RcclComm(e, dist) if dist is not None else None
     dt = 1.0e7 * pkg.hostphys.YEAR
     e.begin_step()
 
     def step():
         e.set_rates_to_zero()
         if comm is not None:
-            # pass, sum over ranks and global pass overlapped slab by slab (parallel.py)
+            # pass, sum over ranks (RCCL inside the library) and global pass overlapped slab by slab
             return comm.pass_allreduce_chemistry(e, dt)
         e.pass_sources(1, 1)
         return e.global_pass(dt)
@@ -192,8 +240,8 @@ def main():
     def barrier():
         e.synchronize()
         torch.cuda.synchronize()
-        if comm is not None:
-            comm.dist.barrier()
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -201,6 +249,7 @@ def main():
     barrier()
     sweep_ms = rates_ms = chem_ms = 0.0
     swept = 0
+    rates_launches = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -209,68 +258,90 @@ def main():
         rates_ms += tm.rates_ms
         chem_ms += tm.chem_ms
         swept += tm.cells_swept
+        rates_launches += tm.rates_launches
     barrier()
     elapsed = time.perf_counter() - t0
-    if comm is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        comm.dist.all_reduce(tt, op=comm.dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        sw = torch.tensor([float(swept)], dtype=torch.float64, device=f"cuda:{local}")
-        comm.dist.all_reduce(sw)
-        swept_total = int(sw.item())
+    mine = {"elapsed": elapsed, "swept": swept, "sweep_ms": sweep_ms, "rates_ms": rates_ms, "chem_ms": chem_ms}
+    if dist is not None and world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
     else:
-        swept_total = swept
+        allr = [mine]
+    elapsed = max(r["elapsed"] for r in allr)
+    swept_total = sum(r["swept"] for r in allr)
 
     if rank == 0:
         units = n ** 3 * total_src * a.steps
         coverage = swept_total / units
-        rates_per_launch_ms = rates_ms / max(1, a.steps * ((a.sources + a.batch - 1) // a.batch))
-        units_per_launch = n ** 3 * min(a.batch, a.sources)
-        achieved = SWEEP_BYTES_PER_CELL_SOURCE * units_per_launch / (rates_per_launch_ms * 1e-3) / 1e9
+        heating = a.heating
+        nl = max(1, rates_launches)
+        rates_per_launch_ms = rates_ms / nl
+        # cell.sources of one k_rates launch on this rank
+        cs_per_launch = swept / nl
+        src_per_launch = cs_per_launch / n ** 3
+        rates_bytes = rates_bytes_per_launch(n ** 3, src_per_launch, heating) if not cfg4 else cs_per_launch * 48.0
+        achieved = rates_bytes / (rates_per_launch_ms * 1e-3) / 1e9
+        headline = (not cfg4) and n == 256 and per_gpu == 8 and batch == 8 and not heating and not a.neutral_start
+        n_instr = stored_counter("k_rates", "SQ_INSTS_VALU") if headline else None
         out = {
             "metric": "cell-updates/sec (grid_cells x sources x iters / wall) on 256^3 box; % HBM roofline",
             "value": units / elapsed, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{'BASELINE configs[2]' if n == 256 and not a.heating else 'variant of BASELINE configs[2]'}: {n}^3 uniform density, {a.sources} sources per GPU "
-                                   f"({total_src} total), {'heating + thermal evolution' if a.heating else 'isothermal 1e4 K'}, "
-                                   f"one evolve3D outer iteration per step",
-                       "mesh": n, "sources_per_gpu": a.sources, "batch": a.batch, "coverage": coverage,
-                       "parallelism": f"sources over {world} GPU(s), all-reduce of rate grids, replicated chemistry"},
+            "scaling": "strong" if cfg4 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[3]: {n}^3 log-normal density, {total_src} sources dealt over {world} GPU(s) "
+                                    f"({per_gpu} on rank 0), neutral start, {'heating' if heating else 'isothermal 1e4 K'}, one evolve3D "
+                                    f"outer iteration per step (the state evolves from step to step)") if cfg4 else
+                                   (f"{'BASELINE configs[2]' if headline or (n == 256 and not heating and not a.neutral_start) else 'variant of BASELINE configs[2]'}: "
+                                    f"{n}^3 uniform density, {per_gpu} sources per GPU ({total_src} total), "
+                                    f"{'heating + thermal evolution' if heating else 'isothermal 1e4 K'}, "
+                                    f"{'neutral start, ' if a.neutral_start else ''}one evolve3D outer iteration per step"),
+                       "mesh": n, "sources_per_gpu": per_gpu, "batch": batch, "coverage": coverage,
+                       "swept_cell_updates_per_s": swept_total / elapsed,
+                       "parallelism": f"sources over {world} GPU(s), RCCL all-reduce of the rate grids inside the library, replicated chemistry"},
+            # the dominant kernel on ITS OWN compulsory bytes: six columns per cell.source, state and rate grids per cell
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("k_rates") if (n == 256 and a.sources == 8 and a.batch == 8) else None,
+                         "traffic": stored_counter("k_rates", "hbm_bytes_per_launch_corrected") if headline else None,
                          "kernel": "k_rates",
-                         "note": "136 B per cell.source (SURVEY 8d) x cells x sources of one launch / mean launch "
-                                 "time (HIP events on the library stream); the kernel is FP64-ALU bound (VALU busy "
-                                 "~85 %, profiles/), not HBM bound"},
-            # the bound that actually holds for k_rates (SURVEY 8d asks for HBM % and FP64 %): VALU issue rate.
-            # wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU) / live launch time, against
-            # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-            "roofline_valu_issue": (lambda n_instr: None if n_instr is None or not (n == 256 and a.sources == 8 and a.batch == 8 and not a.heating) else {
+                         "note": "compulsory bytes of one k_rates launch (48 B of columns per cell.source + 88 B of state and "
+                                 "rate grids per cell) / mean launch time (HIP events on the library's stream); traffic: stored "
+                                 "rocprofv3 --pmc FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of the same command (profiles/). The "
+                                 "kernel is bound by FP64 instruction issue, see roofline_valu_issue"},
+            # SURVEY 8(d)'s figure for the whole of evolve0D (the reference's sweep = column sweep + rates here)
+            "roofline_evolve0d": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                  "achieved": EVOLVE0D_BYTES * swept / ((sweep_ms + rates_ms) * 1e-3) / 1e9,
+                                  "note": "136 B per cell.source (SURVEY 8d) over column sweep + rates time"},
+            # the bound that actually holds for k_rates: VALU issue rate (stored SQ_INSTS_VALU of the same command over
+            # the live launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)
+            "roofline_valu_issue": None if n_instr is None else {
                 "bound": "valu-issue", "unit": "wave-instructions/s", "achieved": n_instr / (rates_per_launch_ms * 1e-3),
                 "peak": 1024 * 2.4e9 / 4.0, "frac": n_instr / (rates_per_launch_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
-                "kernel": "k_rates", "instructions_per_launch": n_instr})(measured_counter("k_rates", "SQ_INSTS_VALU")),
+                "kernel": "k_rates", "instructions_per_launch": n_instr, "instructions": "stored counter (profiles/), live time"},
             "kernel_ms_per_step": {"column_sweep": sweep_ms / a.steps, "rates": rates_ms / a.steps,
                                    "chemistry": chem_ms / a.steps},
-            # the two kernels the north star names, priced the same way (HIP-event time of their launches)
             "roofline_column_sweep": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                      "achieved": COLUMN_BYTES_PER_CELL_SOURCE * n ** 3 * a.sources * a.steps
-                                      / (sweep_ms * 1e-3) / 1e9,
+                                      "achieved": COLUMN_BYTES_PER_CELL_SOURCE * swept / (sweep_ms * 1e-3) / 1e9,
                                       "note": "88 B per cell.source; all shell launches of a step incl. boundary-loss work"},
             "roofline_chemistry": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                    "achieved": CHEM_BYTES_PER_CELL * n ** 3 * a.steps / (chem_ms * 1e-3) / 1e9},
         }
-        for k in ("roofline_column_sweep", "roofline_chemistry"):
+        for k in ("roofline_evolve0d", "roofline_column_sweep", "roofline_chemistry"):
             out[k]["frac"] = out[k]["achieved"] / HBM_PEAK_GBS
-        if not a.no_cpu_baseline and world == 1:
-            port = cpu_baseline(pkg)
+        if world > 1:
+            # per-rank step time (imbalance) and what the kernels of a step do not account for (exposed sum over ranks,
+            # host time)
+            out["per_rank_ms_per_step"] = [1e3 * r["elapsed"] / a.steps for r in allr]
+            out["per_rank_kernel_ms_per_step"] = [(r["sweep_ms"] + r["rates_ms"] + r["chem_ms"]) / a.steps for r in allr]
+        if not a.no_cpu_baseline and world == 1 and not cfg4:
+            out["cpu_baseline"] = cpu_baseline(pkg)
             ref = cpu_baseline_reference()
-            out["cpu_baseline"] = ref if ref is not None else port
-            out["cpu_baseline_port"] = port
+            if ref is not None:
+                out["cpu_baseline_reference"] = ref
         print(json.dumps(out))
-    if comm is not None:
-        comm.dist.destroy_process_group()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    e.close()
 
 
 if __name__ == "__main__":

@@ -955,18 +955,21 @@ static size_t block_doubles(int cap) { // doubles of a column block that holds s
 static int ensure_arena(c2r_ctx *c, size_t need_half, bool *grown) {
   if (grown) *grown = false;
   if (c->d_arena && c->arena_half >= need_half) return 0;
+  // what could be had: 80 % of the memory that is free once the present arena is given back.  Decided BEFORE
+  // anything is freed: a request that cannot be met leaves the arena as it is (the caller shrinks its batch).
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+  const size_t have_b = c->d_arena ? sizeof(double) * 2 * c->arena_half : 0;
+  const size_t limit = (size_t)(0.8 * (double)(free_b + have_b)) / (2 * sizeof(double));
+  if (need_half > limit)
+    return fail(c, "column scratch: two halves of %.1f GB do not fit in %.1f GB of free device memory", need_half * 8e-9,
+                (free_b + have_b) / 1e9);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   if (c->d_arena) HIPCHK(c, hipFree(c->d_arena));
   c->d_arena = nullptr;
   c->arena_half_prev = c->arena_half;
   c->arena_half = 0;
-  size_t free_b = 0, total_b = 0;
-  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-  const size_t limit = (size_t)(0.8 * (double)free_b) / (2 * sizeof(double));
-  if (need_half > limit)
-    return fail(c, "column scratch: two halves of %.1f GB do not fit in %.1f GB of free device memory", need_half * 8e-9,
-                free_b / 1e9);
   // grows geometrically (an allocation of tens of GB takes of the order of a second): at least twice what
   // there was and twice what is asked for now, within the limit
   size_t want = std::min(limit, std::max(std::max(2 * need_half, 2 * c->arena_half_prev), (size_t)1 << 28));

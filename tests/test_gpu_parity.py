@@ -589,6 +589,51 @@ def test_many_faint_sources_batch_invariance_256(pkg, tables):
     assert 128 * 3 < a[0][3] < 128 * 13 and a[0][4] > 0          # boxes really stopped early
 
 
+def test_512_cube_heating_three_seds_properties(pkg, gold):
+    """BASELINE configs[4]'s mesh with its physics: 512^3, heating on, black-body + power-law + quasar SEDs from
+    tables integrated on the device, three box-filling sources.  No oracle at this size: batch 1 against batch 3
+    (identical bits), exact linearity of every rate grid in the fluxes, and the sub-box count of a full mesh."""
+    n = 512
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = np.full(nc, hp.test_density(zred))
+    x0 = 1.0e-3 * (1.0 + 0.5 * np.sin(np.arange(nc, dtype=np.float64) * 1.0e-3))
+    xh = np.concatenate([x0, 1.0 - x0])
+    xhe = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
+    temp = np.full(3 * nc, 1.0e4, dtype=np.float32)
+    t = pkg.RadiationTables.load().add_sed_file(Path(__file__).parent / "golden" / "rad_tables_pl_qpl.npz")
+    with np.load(Path(__file__).parent / "golden" / "sed_setup.npz") as z:
+        t.setup = {k: z[k] for k in z.files}
+    t.build_on_device = True
+    mat = pkg.Material(ndens, xh, xhe, temp, False, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    pos = np.array([[100, 200, 300], [512, 1, 256], [37, 411, 5]], dtype=np.int32)
+    bb, pl, qpl = np.array([1e8, 0.0, 2e8]), np.array([0.0, 3e8, 1e8]), np.array([5e7, 0.0, 0.0])
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+
+    def run(batch, scale):
+        src = pkg.SourceProps(pos, scale * bb, 1.0e48, NormFluxPL=scale * pl, pl_S_star=2.0e48, NormFluxQPL=scale * qpl,
+                              qpl_S_star=0.5e48)
+        e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, t)
+        e.set_batch(batch)
+        e.begin_step()
+        e.set_rates_to_zero()
+        e.pass_sources(1, 1)
+        r = e.download_rates()
+        e.close()
+        return r
+
+    a, b, c = run(1, 1.0), run(3, 1.0), run(3, 2.0)
+    for k in ("phih_grid", "phihe_grid", "phiheat"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(c[k], 2.0 * a[k]), k
+        assert np.all(np.isfinite(a[k])) and np.all(a[k] >= 0) and a[k].max() > 0
+    assert a["sum_nbox"] == b["sum_nbox"] == 3 * 26
+    assert a["photon_loss"][0] == b["photon_loss"][0] and c["photon_loss"][0] == 2.0 * a["photon_loss"][0]
+
+
 def test_512_cube_scratch_beyond_16GiB(pkg, tables):
     """BASELINE configs[4]'s mesh: one 512^3 slot of column scratch is 6.5 GB, so any batch is beyond
     16 GiB.  Two box-filling sources, batch 1 vs batch 2: identical bits, and exact linearity in the flux."""
@@ -847,3 +892,141 @@ def test_three_seds_on_a_random_box_vs_oracle(pkg, orc, tables, gold, iso):
     it = e.download_iter_state()
     assert np.array_equal(it["xh_av"], s.xh_av) and np.array_equal(it["xhe_av"], s.xhe_av)
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Oracle parity at the benchmark's own size and on the production-like workloads (the oracle's sweep in
+# L-infinity shell order over OpenMP threads, bit-identical to its serial sweep: tests/test_oracle_golden.py)
+
+def _threads():
+    import os
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def test_benchmark_size_one_iteration_vs_oracle_256(pkg, orc, otables, tables):
+    """BASELINE configs[2] exactly as bench.py runs it (256^3 uniform density, 8 seeded sources of 1e56 photons/s,
+    gas ionised to x_HI ~ 1e-3 so that every sub-box reaches the full mesh): one outer iteration -- column sweep,
+    rates, global pass -- against the oracle, every grid bit for bit."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    n = 256
+    mat, grid, src, cosmo = bench.config3_inputs(pkg, n, 8)
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, tables)
+    e.set_batch(8)
+    e.begin_step()
+    e.set_rates_to_zero()
+    e.pass_sources(1, 1)
+    rates = e.download_rates()
+    dt = 1.0e7 * pkg.hostphys.YEAR
+    conv = e.global_pass(dt)
+    it = e.download_iter_state()
+    e.close()
+    st = orc.Step(grid.mesh, grid.dr, grid.vol, cosmo.zred, cosmo.H0, cosmo.Omega0, 1, 1.0e4, 1.0, src.srcpos,
+                  src.NormFlux, src.S_star, mat.ndens, mat.reccoef)
+    s = orc.State(st, mat.xh, mat.xhe)
+    orc.begin_step(s)
+    orc.pass_all_sources_shells(otables, st, s, _threads())
+    assert rates["sum_nbox"] == int(s.c.sum_nbox) == 8 * 13
+    assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-13
+    for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)]:
+        assert np.array_equal(rates[k], ref), k
+    assert conv == orc.global_pass_threads(otables, st, s, dt, _threads())
+    for k in ["xh_av", "xhe_av", "xh_intermed", "xhe_intermed"]:
+        assert np.array_equal(it[k], getattr(s, k)), k
+
+
+def test_config3_rank_share_vs_oracle_256(pkg, orc, otables, tables):
+    """BASELINE configs[3] as rank 0 of 8 sees it: 256^3 log-normal density, neutral gas, its 128 of the 1024
+    seeded faint sources (sub-boxes stop after 3-9 rounds: column blocks from the arena, per-tile source lists, the
+    sampled and the full boundary loss): two outer iterations against the oracle, every grid bit for bit."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    n = 256
+    mat, grid, src_all, cosmo = bench.config4_inputs(pkg, n, 1024)
+    pos = np.ascontiguousarray(src_all.srcpos[0::8])
+    flux = np.ascontiguousarray(src_all.NormFlux[0::8])
+    src = pkg.SourceProps(pos, flux, src_all.S_star)
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, tables)
+    e.set_batch(128)
+    e.begin_step()
+    st = orc.Step(grid.mesh, grid.dr, grid.vol, cosmo.zred, cosmo.H0, cosmo.Omega0, 1, 1.0e4, 1.0, pos, flux, src.S_star,
+                  mat.ndens, mat.reccoef)
+    s = orc.State(st, mat.xh, mat.xhe)
+    orc.begin_step(s)
+    dt = 1.0e7 * pkg.hostphys.YEAR
+    for it_no in range(2):
+        e.set_rates_to_zero()
+        e.pass_sources(1, 1)
+        rates = e.download_rates()
+        conv = e.global_pass(dt)
+        it = e.download_iter_state()
+        orc.pass_all_sources_shells(otables, st, s, _threads())
+        assert rates["sum_nbox"] == int(s.c.sum_nbox), it_no
+        assert 128 * 2 < rates["sum_nbox"] < 128 * 12
+        assert rel_err(rates["photon_loss"][0], s.photon_loss[0]) <= 1e-13
+        for k, ref in [("phih_grid", s.phih), ("phihe_grid", s.phihe)]:
+            assert np.array_equal(rates[k], ref), (it_no, k)
+        assert conv == orc.global_pass_threads(otables, st, s, dt, _threads()), it_no
+        for k in ["xh_av", "xhe_av", "xh_intermed", "xhe_intermed"]:
+            assert np.array_equal(it[k], getattr(s, k)), (it_no, k)
+    e.close()
+
+
+def test_config4_workload_full_evolve3d_vs_oracle(pkg, orc, gold):
+    """The workload of BASELINE configs[4] at a size the oracle affords: 64^3 log-normal density, neutral gas,
+    16 faint sources, heating on, black-body + power-law + quasar SEDs, the tables integrated on the device
+    (c2r_build_tables) -- a whole evolve3D call to convergence (c2r_evolve3d), against the oracle's loop: the same
+    number of outer iterations, the same non-converged count after every one of them, every final grid bit for
+    bit."""
+    n, nsrc = 64, 16
+    rng = np.random.default_rng(64016)
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 1.0, nc) - 0.5)
+    eps = 1.0e-20
+    xh = np.concatenate([np.full(nc, 1.0 - eps), np.full(nc, eps)])
+    xhe = np.concatenate([np.full(nc, 1.0 - 2 * eps), np.full(nc, eps), np.full(nc, eps)])
+    temp = np.full(3 * nc, 1.0e4, dtype=np.float32)
+    srcpos = rng.integers(1, n + 1, size=(nsrc, 3)).astype(np.int32)
+    bb = 10.0 ** rng.uniform(4.0, 6.0, nsrc)                 # 1e52 .. 1e54 photons/s
+    idx = np.arange(nsrc)
+    pl = np.where(idx % 3 == 0, 0.3 * bb, 0.0)
+    qpl = np.where(idx % 5 == 0, 0.5 * bb, 0.0)
+    t = pkg.RadiationTables.load().add_sed_file(Path(__file__).parent / "golden" / "rad_tables_pl_qpl.npz")
+    with np.load(Path(__file__).parent / "golden" / "sed_setup.npz") as z:
+        t.setup = {k: z[k] for k in z.files}
+    t.build_on_device = True
+    with np.load(pkg.evolve.DEFAULT_TABLES) as z:
+        d = {k: z[k] for k in z.files}
+    zz = gold("rad_tables_pl_qpl.npz")
+    d.update({k: zz[k] for k in zz.files})
+    T = orc.Tables(d)
+    mat = pkg.Material(ndens, xh.copy(), xhe.copy(), temp.copy(), False, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    src = pkg.SourceProps(srcpos, bb, 1.0e48, NormFluxPL=pl, pl_S_star=2.0e48, NormFluxQPL=qpl, qpl_S_star=0.5e48)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, t)
+    dt = 1.0e7 * hp.YEAR
+    niter, flags = e.evolve3d(dt)
+    e.download_state(mat)
+    e.close()
+    st = orc.Step((n, n, n), dr, vol, zred, hp.H0, hp.Omega0, False, 1.0e4, 1.0, srcpos, bb, 1.0e48, ndens, hp.reccoef(1.0e4),
+                  normflux_pl=pl, normflux_qpl=qpl, pl_s_star=2.0e48, qpl_s_star=0.5e48)
+    s = orc.State(st, xh, xhe, temp)
+    orc.begin_step(s)
+    # evolve3D's loop (evolve.F90:147-217) around the oracle's threaded pass and global pass
+    crit = min(int(np.float32(2.5e-4) * n ** 3), nsrc)
+    it, conv, ref_flags = 0, nc, []
+    while not (conv < crit and it > 1) and it <= 500:
+        it += 1
+        orc.pass_all_sources_shells(T, st, s, _threads())
+        conv = orc.global_pass_threads(T, st, s, dt, _threads())
+        ref_flags.append(conv)
+    assert niter == it and flags == ref_flags, (niter, it, flags[:5], ref_flags[:5])
+    assert niter > 3
+    assert np.array_equal(mat.xh, s.xh_intermed) and np.array_equal(mat.xhe, s.xhe_intermed)
+    assert np.array_equal(np.asarray(mat.temperature_grid)[:2 * nc], np.asarray(s.temperature)[:2 * nc])
