@@ -2186,6 +2186,38 @@ static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first,
   return 0;
 }
 
+static int ensure_chemistry_buffers(c2r_ctx *c) {
+  if (!c->isothermal && !c->d_defer[0]) {
+    for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
+    HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (2 + CHEM_HIST))); // two list counts, then the histogram
+    HIPCHK(c, hipMemset(c->d_chemctl, 0, sizeof(int) * (2 + CHEM_HIST)));
+  }
+  return 0;
+}
+
+// evolve0D_global(dt,pos,conv_flag) (files_for_3D/evolve_point.F90:325-440) for ONE cell, as the reference's
+// global_pass calls it (evolve.F90:477-484): applies the collected rates to the cell at 1-based mesh position
+// pos and adds 1 to conv_flag if the cell has not converged.  A whole pass is c2r_global_pass; this entry point
+// exists for hosts written against the per-cell interface (one launch and one synchronisation per call).
+extern "C" int c2r_evolve0d_global(c2r_ctx *c, double dt, const int pos[3], int *conv_flag) {
+  if (!c || !pos) return 1;
+  if (check_ready(c, "c2r_evolve0d_global")) return 1;
+  const Grid g = c->g;
+  if (pos[0] < 1 || pos[0] > g.n1 || pos[1] < 1 || pos[1] > g.n2 || pos[2] < 1 || pos[2] > g.n3)
+    return fail(c, "c2r_evolve0d_global: position (%d,%d,%d) outside the mesh", pos[0], pos[1], pos[2]);
+  HIPCHK(c, hipSetDevice(c->device));
+  if (ensure_chemistry_buffers(c)) return 1;
+  const size_t q = (size_t)(pos[0] - 1) + (size_t)g.n1 * ((size_t)(pos[1] - 1) + (size_t)g.n2 * (size_t)(pos[2] - 1));
+  HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
+  if (launch_chemistry(c, c->stream, dt, q, 1, nullptr, 0, c->d_defer[0], c->d_chemctl)) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (conv_flag) *conv_flag += *c->h_conv;
+  for (c2r_ctx *r : c->replicas) // the other devices of a multi-device context keep the same state
+    if (c2r_evolve0d_global(r, dt, pos, nullptr)) { c->err = r->err; return 1; }
+  return 0;
+}
+
 extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, size_t ncells, void *after_event) {
   if (!c) return 1;
   if (check_ready(c, "c2r_global_pass_cells")) return 1;
@@ -2193,10 +2225,7 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
   const Grid g = c->g;
   if (first_cell > g.ncell || ncells > g.ncell - first_cell) return fail(c, "c2r_global_pass_cells: range outside the mesh");
   const bool heat = !c->isothermal;
-  if (heat && !c->d_defer[0]) {
-    for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * g.ncell));
-    HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (2 + CHEM_HIST))); // two list counts, then the histogram
-  }
+  if (ensure_chemistry_buffers(c)) return 1;
   if (first_cell == 0) {
     HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
     if (heat) HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (2 + CHEM_HIST), c->stream));

@@ -287,6 +287,14 @@ module c2ray_hip
        real(c_double), intent(out) :: out5(5)
      end function c2r_fraction_means
 
+     integer(c_int) function c2r_evolve0d_global(ctx, dt, pos, conv_flag) bind(C, name="c2r_evolve0d_global")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: dt
+       integer(c_int), intent(in) :: pos(3)
+       integer(c_int), intent(inout) :: conv_flag
+     end function c2r_evolve0d_global
+
      integer(c_int) function c2r_fraction_minima(ctx, which, out2) bind(C, name="c2r_fraction_minima")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

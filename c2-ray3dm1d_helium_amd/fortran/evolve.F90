@@ -58,6 +58,9 @@ module evolve
   ! the reference's own master_slave.F90, unmodified: its do_source calls land in our evolve_source
   use master_slave_processing, only: do_grid
 #endif
+#ifdef C2RAY_GLOBAL_PASS_BY_CELL
+  use evolve_point, only: evolve0D_global
+#endif
   use, intrinsic :: iso_c_binding
   use c2ray_hip
 
@@ -287,6 +290,9 @@ contains
 
     integer(c_int) :: cf
     real(kind=dp) :: means(5), n_now(5), minima(2)
+#ifdef C2RAY_GLOBAL_PASS_BY_CELL
+    integer :: i,j,k
+#endif
 
     ! mean photon loss per cell (evolve.F90:457)
     photon_loss(:)=photon_loss_all(:)/(real(mesh(1))*real(mesh(2))*real(mesh(3)))
@@ -299,8 +305,20 @@ contains
     endif
 
     if (rank == 0) write(logf,*) 'Doing global '
+#ifdef C2RAY_GLOBAL_PASS_BY_CELL
+    ! the reference's own loop (evolve.F90:477-484) over the per-cell interface of module evolve_point
+    conv_flag=0
+    do k=1,mesh(3)
+       do j=1,mesh(2)
+          do i=1,mesh(1)
+             call evolve0D_global (dt,(/ i,j,k /),conv_flag)
+          enddo
+       enddo
+    enddo
+#else
     call check (c2r_global_pass (hip_ctx, dt, cf), "c2r_global_pass")
     conv_flag=cf
+#endif
 
     if (rank == 0) then
        call check (c2r_fraction_means (hip_ctx, 1_c_int, means), "c2r_fraction_means")

@@ -213,6 +213,11 @@ void *c2r_rates_device_ptr(c2r_ctx *ctx);
 int c2r_set_rates_buffer(c2r_ctx *ctx, void *device_ptr, size_t count);
 int c2r_synchronize(c2r_ctx *ctx);
 
+/* evolve0D_global(dt,pos,conv_flag) (files_for_3D/evolve_point.F90:325-440) for the ONE cell at 1-based mesh
+ * position pos, as the reference's global_pass calls it cell by cell (evolve.F90:477-484): applies the
+ * collected rates, adds 1 to *conv_flag when the cell has not converged.  c2r_global_pass is the whole pass. */
+int c2r_evolve0d_global(c2r_ctx *ctx, double dt, const int pos[3], int *conv_flag);
+
 /* minval(xh(:,:,:,0)), minval(xhe(:,:,:,0)) of the grids `which` selects as in c2r_fraction_means: the
  * "min xh_av / min xhe_av" log lines of global_pass (evolve.F90:463-466) want which = 2. */
 int c2r_fraction_minima(c2r_ctx *ctx, int which, double out2[2]);

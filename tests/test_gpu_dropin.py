@@ -24,6 +24,9 @@ sys.path.insert(0, str(ROOT / "oracle"))
     # C2Ray_3D_hip_dogrid: the reference's own master_slave.F90 (unmodified) deals out the sources and calls
     # do_source of the product's module evolve_source -- the do_source call surface, one source per call
     (False, "dogrid", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
+    # C2Ray_3D_hip_bycell: the global pass through the per-cell interface of the product's module evolve_point
+    # (evolve0D_global for every cell, the reference's own loop)
+    (False, "bycell", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
     # C2RAY_HIP_BUILD_TABLES=1: the shim has the photo-ionisation / heating tables integrated on the device
     # (c2r_build_tables) instead of uploading rad_ini's host arrays
     (False, "devtables", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
@@ -49,12 +52,13 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         monkeypatch.setenv("C2RAY_HIP_NGPU", "2")
         monkeypatch.setenv("C2RAY_HIP_SAME_DEVICE", "1")
     comm1, ngpu2 = pl == "comm1", pl == "ngpu2"
+    bycell = pl == "bycell"
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
-    which_hip = "hip_dogrid" if dogrid else "hip"
+    which_hip = "hip_dogrid" if dogrid else ("hip_bycell" if bycell else "hip")
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "")
     r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl, lls=lls)
     r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls)
     files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
