@@ -104,3 +104,64 @@ def iteration_times(run) -> list[float]:
         if m:
             out.append(float(m.group(2)))
     return out
+
+
+def run_cubep3m(mesh: int, sources, *, seed=2024, T0=1e4, isothermal=False, steps_per_slice=2, which="test",
+                name=None, zred=(9.0, 8.6), lls_scale=1.0, timeout=3600):
+    """Run a binary of the cubep3m-material build (oracle/ref_build.sh N cubep3m: ../cubep3m.F90 +
+    mat_ini_cubep3m.F90, type_of_clumping = 5, use_LLS with type_of_LLS = 2) on generated inputs in the formats
+    of files_for_3D/mat_ini_cubep3m.F90:
+      <root>/coarser_densities/halos_removed/<z>n_all.dat    density (:223-351): stream, 3 x int32 mesh header,
+                                                             float32 N^3 in N-body grid units, seeded log-normal
+      <root>/coarser_densities/halos_included/<z>n_all.dat   clumping input (:675-760), same format
+      <root>/halos/<z>cross_section.bin                      Lyman-limit cross sections (:859-920), same format
+      <root>/run/redshifts.dat, test_sources.dat, input      run directory (cwd)
+    sources: (i, j, k, S_BB, S_PL, S_QPL) as for the -DPL -DQUASARS test build.  Returns <root>/run."""
+    exe = REFDIR / f"N{mesh}_cubep3m" / f"C2Ray_3D_{which}"
+    if not exe.exists():
+        raise FileNotFoundError(f"{exe} missing: run oracle/ref_build.sh {mesh} cubep3m")
+    root = REFDIR / (name or f"run_cubep3m_N{mesh}")
+    if root.exists():
+        shutil.rmtree(root)
+    run = root / "run"
+    (run / "results").mkdir(parents=True)
+    (run / "sources").mkdir()
+    d_rem = root / "coarser_densities" / "halos_removed"
+    d_inc = root / "coarser_densities" / "halos_included"
+    d_lls = root / "halos"
+    for d in (d_rem, d_inc, d_lls):
+        d.mkdir(parents=True)
+    rng = np.random.default_rng(seed)
+    n_box = 8000.0                                       # cubep3m.F90:43
+    mean = (n_box / mesh) ** 3                           # N-body grid cells per coarse cell = mean density in "grid" units
+    hdr = np.array([mesh, mesh, mesh], dtype=np.int32).tobytes()
+    for z in zred[:-1]:
+        zs = f"{z:6.3f}".strip()
+        dens = (mean * np.exp(rng.normal(0.0, 0.8, mesh ** 3) - 0.32)).astype(np.float32)
+        (d_rem / f"{zs}n_all.dat").write_bytes(hdr + dens.tobytes())
+        clump = (dens * np.exp(rng.normal(0.0, 0.3, mesh ** 3))).astype(np.float32)
+        (d_inc / f"{zs}n_all.dat").write_bytes(hdr + clump.tobytes())
+        lls = (lls_scale * 10.0 ** rng.uniform(-0.5, 0.5, mesh ** 3)).astype(np.float32)
+        (d_lls / f"{zs}cross_section.bin").write_bytes(hdr + lls.tobytes())
+    (root / "tables").symlink_to(REFDIR / "tables")      # cooling curves, read from ../tables (cooling_h.f90:83-149)
+    (d_inc / "clumping_fit.dat").write_text("9.0 0.0 1.0 0.0 0.0\n")
+    (run / "redshifts.dat").write_text(f"{len(zred)}\n" + "".join(f"{z:.3f}\n" for z in zred))
+    # sourceprops_test.F90:111 reads dir_src // "test_sources.dat", and dir_src is cubep3m.F90's "./sources/"
+    with open(run / "sources" / "test_sources.dat", "w") as f:
+        f.write(f"{len(sources)}\n")
+        for src in sources:
+            f.write(f"{src[0]} {src[1]} {src[2]} " + " ".join(f"{x:.6e}" for x in src[3:]) + "\n")
+    with open(run / "input", "w") as f:
+        f.write("0 1 1 0 0\n")                           # output streams (output.F90:90)
+        f.write(f"{T0:g}\n")                             # mat_ini (mat_ini_cubep3m.F90:131-165)
+        f.write("y\n" if isothermal else "n\n")
+        f.write("n\nn\n1\n")
+        f.write("clumping_fit.dat\n")
+        f.write("redshifts.dat\n")                       # nbody_ini (cubep3m.F90:203)
+        f.write(f"{steps_per_slice}\n1\n")               # time_ini
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = "1"
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib/llvm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    with open(run / "stdout.txt", "w") as so:
+        subprocess.run([str(exe), "input"], cwd=run, env=env, stdout=so, stderr=subprocess.STDOUT, timeout=timeout, check=True)
+    return run

@@ -135,3 +135,34 @@ def test_random_source_lists_through_both_binaries():
         for f in files:
             assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), (ic, sources, iso, f)
         assert refrun.parse_log(r1) == refrun.parse_log(r2), (ic, sources, iso)
+
+
+def test_cubep3m_material_through_the_dropin():
+    """The material side of the production target C2Ray_3D_cubep3m_kyl_periodic (files_for_3D/Makefile:207-210)
+    through the drop-in: the reference's own cubep3m.F90 + mat_ini_cubep3m.F90 read a generated snapshot in the
+    cubep3m formats -- `<z>n_all.dat` density (stream, 3 x int32 header + float32 N^3, mat_ini_cubep3m.F90:223-351),
+    the halos-included grid behind type_of_clumping = 5 and the cross-section grid behind use_LLS / type_of_LLS = 2
+    (oracle/refrun.py:run_cubep3m writes them, seeded) -- with -DPL -DQUASARS sources and heating; once linked with
+    the reference's evolve chain, once with the product's modules + libc2ray_hip.so.  Two time steps of 501 outer
+    iterations each (a handful of cells in the position-dependent clumping field never settle, so both runs go to
+    the iteration cap): every output file byte-identical, the same non-converged count after every iteration.
+    (The target's own source module, sourceprops_cubep3m.F90, has unbalanced ENDIFs at :307 and :397 in this
+    snapshot of the reference and compiles with no compiler, so the sources come through sourceprops_test.F90.)"""
+    import refrun
+    ref = refrun.REFDIR / "N16_cubep3m" / "C2Ray_3D_test"
+    hip = refrun.REFDIR / "N16_cubep3m" / "C2Ray_3D_hip"
+    if not ref.exists() or not hip.exists():
+        pytest.skip("oracle/_ref/N16_cubep3m binaries not present (built only where /root/reference exists)")
+    sources = [(8, 8, 8, 3e59, 1e59, 0.0), (2, 15, 4, 0.0, 5e58, 2e59), (16, 1, 9, 2e59, 0.0, 5e58)]
+    r1 = refrun.run_cubep3m(16, sources, which="test", name="dropin_cubep3m_ref")
+    r2 = refrun.run_cubep3m(16, sources, which="hip", name="dropin_cubep3m_hip")
+    files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
+    assert len(files) >= 10, files
+    for f in files:
+        assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), f
+    a, b = refrun.parse_log(r1), refrun.parse_log(r2)
+    assert a == b and len(a) == 2 and len(a[0]) > 100
+    log1 = (r1 / "results" / "C2Ray.log").read_text(errors="replace")
+    assert "clumping input from ../coarser_densities/halos_included/9.000n_all.dat" in log1
+    assert "density input from ../coarser_densities/halos_removed/9.000n_all.dat" in log1
+    assert "(type  5 )" in log1 and "(type  2 )" in log1
