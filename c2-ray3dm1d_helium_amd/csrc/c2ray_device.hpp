@@ -880,6 +880,27 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
   }
 }
 
+// phi_photo_out of ONE band of SED `sed` (photo_lookuptable, radiation_photoionrates.f90:331-464): the term
+// photo_out_only / photo_out_multi add up in band order.  Used on its own by the sampled boundary loss, where
+// any subset of these non-negative terms, in any order, is a valid lower bound.
+C2R_HD double photo_out_band(const BandData &bd, int sed, const double *photo_thick, const double *photo_thin, int b,
+                             double cin_HI, double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII,
+                             double cout_HeII, double NFlux) {
+  const double sHI = bd.sigma_HI[b], sHeI = bd.sigma_HeI[b], sHeII = bd.sigma_HeII[b];
+  const double tau_in = cin_HI * sHI + cin_HeI * sHeI + cin_HeII * sHeII;
+  if (tau_in >= bd.tau_zero[sed][b]) return 0.0; // phi_out = +0 exactly (band_tau_zero)
+  const double tau_out = cout_HI * sHI + cout_HeI * sHeI + cout_HeII * sHeII;
+  const double *tk = photo_thick + (size_t)b * NTAUP;
+  if (fabs(tau_out - tau_in) > tau_photo_limit) {
+    const TauPos pout = tau_table_position(tau_out);
+    return NFlux * read_table(tk, pout);
+  }
+  const TauPos pin = tau_table_position(tau_in);
+  const double phi_in = NFlux * read_table(tk, pin);
+  const double phi_all = NFlux * (tau_out - tau_in) * read_table(photo_thin + (size_t)b * NTAUP, pin);
+  return phi_in - phi_all;
+}
+
 C2R_HD double photo_out_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                               double cout_HeI, double cin_HeII, double cout_HeII, const double *NFlux) {
   double total = 0.0;

@@ -241,6 +241,68 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// A quick LOWER BOUND of that loss, to decide "this source goes on" without waiting for the full sum: of every
+// `sample`-th block of the round's shells, 8 cells (every 32nd), each cell's bands spread over 32 lanes -- a thread
+// evaluates one or two bands, so the launch lasts microseconds where a thread of k_loss walks all bands of
+// its cell.  Every term is a non-negative photon count, so any subset, in any order, bounds the loss from below;
+// a bound that clears the threshold of evolve_source.F90:136 with a factor 2 to spare is decisive, anything else
+// is replaced by the full sum of k_loss.  No bit of any result depends on this kernel.
+__global__ void __launch_bounds__(BLOCK)
+k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int multi, int s_lo, int s_hi, Box box,
+             StepScalars sc, const double *__restrict__ arena, const BandData *__restrict__ bd, SedSet ss,
+             const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
+  __shared__ double sh[BLOCK / 64];
+  const SrcDev &S = src[list[blockIdx.y]];
+  const int B = block_base[s_lo] + (int)blockIdx.x * sample;
+  int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_base[mid] <= B) lo = mid; else hi = mid - 1;
+  }
+  const int shell = lo;
+  const long long cnt = shell_count(shell);
+  const int slot = threadIdx.x & 31;
+  const long long t = (long long)(B - block_base[shell]) * BLOCK + (threadIdx.x >> 5) * 32;
+  double loss = 0.0;
+  if (t < cnt) {
+    int di, dj, dk;
+    shell_decode(shell, (int)t, di, dj, dk);
+    const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
+                        dk <= box.hi[2];
+    const bool boundary = di == box.lo[0] || dj == box.lo[1] || dk == box.lo[2] || di == box.hi[0] || dj == box.hi[1] ||
+                          dk == box.hi[2];
+    if (inside && boundary) {
+      const size_t cz = S.cz;
+      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
+      const double *cs = arena + S.col;
+      const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
+      const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
+      if (cin_HI < max_coldensh) {
+        double vol_ph;
+        if (shell == 0) {
+          vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
+        } else {
+          const double path = sc_path(di, dj, dk) * sc.dr1;
+          const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
+          vol_ph = 4.0 * pi * (xs * xs + ys * ys + zs * zs) * path;
+        }
+        const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+        double po = 0.0;
+        for (int sd = 0; sd < (multi ? NSED : 1); sd++) {
+          if (!(nf[sd] > 0.0)) continue;
+          for (int b = ss.lo[sd] + slot; b < ss.hi[sd]; b += 32)
+            po += photo_out_band(*bd, sd, ss.photo_thick[sd], ss.photo_thin[sd], b, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII,
+                                 cout_HeII, nf[sd]);
+        }
+        loss = po * sc.vol / vol_ph;
+      }
+    }
+  }
+  const double bs = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + blockIdx.x] = bs;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column sweep of one shell for every active source of the batch (blockIdx.y counts `active`).
 // evolve0D, files_for_3D/evolve_point.F90:114-168 and :237-244, with cinterp (column_density.f90:28-345).
 // A source's column block in the arena: [6][cz] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII), each array in SHELL
@@ -845,6 +907,10 @@ struct c2r_ctx {
   size_t list_cap = 0;             // ints per set
   double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
   size_t loss_partial_cap = 0;     // doubles
+  // the sampled loss of a round is read back one round later (the sweep goes on meanwhile): two slots
+  double *d_probe_partial[2] = {nullptr, nullptr}, *d_probe_acc = nullptr, *h_probe = nullptr;
+  size_t probe_partial_cap[2] = {0, 0};
+  hipEvent_t ev_probe[2] = {nullptr, nullptr};
   // rates launches: listed tiles, and for each the sources that reach it (CSR), per set (h: pinned)
   int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr};
   int *d_tptr[2] = {nullptr, nullptr}, *h_tptr[2] = {nullptr, nullptr};
@@ -1078,6 +1144,9 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   }
   CR(hipMalloc(&c->d_loss_acc, sizeof(double) * BATCH_MAX));
   CR(hipHostMalloc(&c->h_loss, sizeof(double) * BATCH_MAX));
+  CR(hipMalloc(&c->d_probe_acc, sizeof(double) * 2 * BATCH_MAX));
+  CR(hipHostMalloc(&c->h_probe, sizeof(double) * 2 * BATCH_MAX));
+  for (int k = 0; k < 2; k++) CR(hipEventCreateWithFlags(&c->ev_probe[k], hipEventDisableTiming));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
   CR(hipHostMalloc(&c->h_conv, sizeof(int)));
   CR(hipMalloc(&c->d_bands, sizeof(BandData)));
@@ -1107,6 +1176,12 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
+  if (c->h_probe) (void)hipHostFree(c->h_probe);
+  for (int k = 0; k < 2; k++) {
+    if (c->d_probe_partial[k]) (void)hipFree(c->d_probe_partial[k]);
+    if (c->ev_probe[k]) (void)hipEventDestroy(c->ev_probe[k]);
+  }
+  if (c->d_probe_acc) (void)hipFree(c->d_probe_acc);
   for (int k = 0; k < 2; k++) {
     void *dev[] = {c->d_tiles[k], c->d_tptr[k], c->d_tsrc[k], c->d_src[k], c->d_list[k]};
     void *host[] = {c->h_tiles[k], c->h_tptr[k], c->h_tsrc[k], c->h_src[k], c->h_list[k]};
@@ -1653,6 +1728,32 @@ static int boundary_loss(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, 
   return 0;
 }
 
+constexpr int PROBE_SAMPLE = 16; // the probe looks at 8 cells of every 16th block of the round's shells
+
+// Queue the probe of the round's loss for the sources d_list[set][list_off .. +n) into slot `slot` (results in
+// c->h_probe + slot * BATCH_MAX once c->ev_probe[slot] has happened).  Does not wait.
+static int launch_probe(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, int s_hi, const Box &box, int slot,
+                        const StepScalars &sc, const SedSet &ss, bool multi) {
+  const int count = c->block_base[s_hi + 1] - c->block_base[s_lo];
+  const int nblk = (count + PROBE_SAMPLE - 1) / PROBE_SAMPLE;
+  const size_t need = (size_t)nblk * n;
+  if (c->probe_partial_cap[slot] < need) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ensure_pair<double>(c, &c->d_probe_partial[slot], (double **)nullptr, &c->probe_partial_cap[slot], need)) return 1;
+  }
+  hipLaunchKernelGGL(k_loss_probe, dim3(nblk, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
+                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_arena, c->d_bands, ss, c->d_block_base, c->d_probe_partial[slot], nblk,
+                     PROBE_SAMPLE);
+  hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, c->stream, c->d_probe_partial[slot], nblk, nblk,
+                     c->d_probe_acc + (size_t)slot * BATCH_MAX);
+  c->tm.sweep_launches += 2;
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_probe + (size_t)slot * BATCH_MAX, c->d_probe_acc + (size_t)slot * BATCH_MAX, sizeof(double) * n,
+                           hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_probe[slot], c->stream));
+  return 0;
+}
+
 // do_source (evolve_source.F90:66-238) for every source number in `mine`, up to c->batch at a time.
 // Per batch: the column sweep (dependent shell launches, host test of the sub-box loop) on the
 // high-priority stream, then ONE rates launch for the whole batch on the second stream; the next
@@ -1777,28 +1878,80 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     size_t list_used = 0;
     long long batch_cells = 0;
     int *hl = c->h_list[set];
-    std::vector<int> undecided;
+    // The sub-box loop (evolve_source.F90:136-144), pipelined one round deep.  After the shells of round r a probe of
+    // the round's boundary loss is queued, but its result is only needed to know who sweeps round r+1.  When every
+    // active source went beyond round r in the previous pass (prev_nbox), round r+1 is launched at once for all of
+    // them and the probe is read afterwards, while those shells run: the device never waits for the host.  A
+    // source that turns out to have stopped at r keeps round r as its last -- its shells of round r+1 are
+    // never looked at (the rates launch only sees the final box), so a wrong guess costs time, never a bit.
+    struct Pending { // a probe in flight
+      bool on = false;
+      int round = 0, slot = 0, nact = 0, s_lo = 0, s_hi = 0;
+      size_t off = 0;
+      Box box{};
+    } pend;
+    // read a probe, replace what it leaves undecided by the full sum, apply the while-test: sources that stop get
+    // active = false and the round as their last
+    auto settle = [&](Pending &P) -> int {
+      if (!P.on) return 0;
+      P.on = false;
+      HIPCHK(c, hipEventSynchronize(c->ev_probe[P.slot]));
+      const double *probe = c->h_probe + (size_t)P.slot * BATCH_MAX;
+      const int *lst = hl + P.off;
+      std::vector<int> undecided;
+      for (int a = 0; a < P.nact; a++) {
+        SrcRun &r = run[lst[a]];
+        if (!r.active) continue; // stopped at an earlier round: swept this one on trust, to no effect
+        r.loss = probe[a];
+        if (!(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) undecided.push_back(lst[a]);
+      }
+      if (!undecided.empty()) {
+        int *ul = hl + list_used;
+        std::copy(undecided.begin(), undecided.end(), ul);
+        HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, ul, sizeof(int) * undecided.size(), hipMemcpyHostToDevice, c->stream));
+        if (boundary_loss(c, set, list_used, (int)undecided.size(), P.s_lo, P.s_hi, P.box, 1, sc, ss, multi)) return 1;
+        list_used += undecided.size();
+        for (size_t j = 0; j < undecided.size(); j++) run[undecided[j]].loss = c->h_loss[j];
+      }
+      for (int a = 0; a < P.nact; a++) {
+        SrcRun &r = run[lst[a]];
+        if (!r.active) continue;
+        if (!(r.loss > C2R_F(1e-10) * r.total_flux)) { // evolve_source.F90:136: the box does not grow any more
+          r.active = false;
+          r.nbox = P.round;
+        }
+      }
+      return 0;
+    };
+    size_t cur_off = 0; // the active list of the last round launched
+    int cur_nact = 0;
     for (int round = 1;; round++) {
-      // while-test of evolve_source.F90:136-139 per source; all sources that pass are in round `round`
       const Box box = round_box(reach, round);
       const int s_hi = box_smax(box);
+      // may this round start before the previous round's probe has been read?
+      bool ahead = pend.on && cur_nact > 0;
+      if (ahead)
+        for (int a = 0; a < cur_nact && ahead; a++) ahead = c->prev_nbox[(size_t)run[hl[cur_off + a]].ns - 1] >= round;
+      if (!ahead && settle(pend)) return 1;
+      // who sweeps this round: the while-test of evolve_source.F90:136-139 (its loss part taken on trust when ahead)
       int nact = 0;
       int *act = hl + list_used;
       int s_lo = 1 << 30;
       for (int b = 0; b < nb; b++) {
         SrcRun &r = run[b];
         if (!r.active) continue;
-        const Box cur = round_box(reach, r.nbox);
-        if (!(r.loss > C2R_F(1e-10) * r.total_flux && box_can_grow(reach, cur))) {
+        if (!box_can_grow(reach, round_box(reach, r.nbox)) || !(ahead || r.loss > C2R_F(1e-10) * r.total_flux)) {
           r.active = false;
           continue;
         }
-        r.nbox++;
-        r.loss = 0.0;
+        r.nbox = round;
         act[nact++] = b;
         s_lo = std::min(s_lo, r.smax_prev + 1);
       }
-      if (nact == 0) break;
+      if (nact == 0) {
+        if (settle(pend)) return 1;
+        break;
+      }
       if (s_hi > g.smax) return fail(c, "internal: shell %d beyond smax %d", s_hi, g.smax);
       // blocks too small for this round move to larger ones (the shells stored so far are a prefix of every array)
       for (int a = 0; a < nact; a++) {
@@ -1831,52 +1984,53 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         r.cap = ncap;
         HIPCHK(c, hipMemcpyAsync(c->d_src[set] + act[a], &S, sizeof(SrcDev), hipMemcpyHostToDevice, c->stream));
       }
-      HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, act, sizeof(int) * nact, hipMemcpyHostToDevice, c->stream));
+      // the same sources as in the last round: the list is on the device already
+      size_t act_off = list_used;
+      if (cur_nact == nact && round > 1 && std::equal(act, act + nact, hl + cur_off)) {
+        act_off = cur_off;
+      } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, act, sizeof(int) * nact, hipMemcpyHostToDevice, c->stream));
+        list_used += (size_t)nact;
+      }
+      cur_off = act_off;
+      cur_nact = nact;
       for (int s = s_lo; s <= s_hi; s++) {
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
         const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
-        hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + list_used,
+        hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + act_off,
                            s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_arena,
                            c->lls_on_grid ? c->d_lls : nullptr);
         c->tm.sweep_launches++;
       }
       HIPCHK(c, hipGetLastError());
-      const size_t act_off = list_used;
-      list_used += (size_t)nact;
-      {
-        long long cells = box_cells(box) - (round > 1 ? box_cells(round_box(reach, round - 1)) : 0);
-        batch_cells += cells * nact;
-      }
-      for (int a = 0; a < nact; a++) run[act[a]].smax_prev = s_hi;
+      for (int a = 0; a < nact; a++) run[hl[act_off + a]].smax_prev = s_hi;
+      // the probe of the round before, if this round went ahead of it: sources it stops keep that round as their
+      // last (and drop out of the lists from the next round on)
+      if (settle(pend)) return 1;
       if (!box_can_grow(reach, box)) {
         // The while-test after this round fails whatever the loss: the round is every active source's last, and
         // its loss (the one that is kept, evolve_source.F90:233) is evaluated after the sweep, beside the rates.
         for (int a = 0; a < nact; a++) {
-          run[act[a]].final_loss_due = true;
-          run[act[a]].active = false;
+          SrcRun &r = run[hl[act_off + a]];
+          if (!r.active) continue; // stopped a round earlier after all
+          r.final_loss_due = true;
+          r.active = false;
         }
         break;
       }
-      // The loss of this round decides whether the source goes on.  A sampled loss (a lower bound) that clears
-      // the threshold with a factor 2 to spare decides "continue" and is never looked at again; anything else is
-      // replaced by the full sum.
-      if (boundary_loss(c, set, act_off, nact, s_lo, s_hi, box, LOSS_SAMPLE, sc, ss, multi)) return 1;
-      undecided.clear();
-      for (int a = 0; a < nact; a++) {
-        SrcRun &r = run[act[a]];
-        r.loss = c->h_loss[a];
-        if (!(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) undecided.push_back(act[a]);
-      }
-      if (!undecided.empty()) {
-        int *ul = hl + list_used;
-        std::copy(undecided.begin(), undecided.end(), ul);
-        HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, ul, sizeof(int) * undecided.size(), hipMemcpyHostToDevice, c->stream));
-        if (boundary_loss(c, set, list_used, (int)undecided.size(), s_lo, s_hi, box, 1, sc, ss, multi)) return 1;
-        list_used += undecided.size();
-        for (size_t j = 0; j < undecided.size(); j++) run[undecided[j]].loss = c->h_loss[j];
-      }
+      // The loss of this round decides whether a source goes on: queue its probe, read it in the next round.
+      pend.on = true;
+      pend.round = round;
+      pend.slot = round & 1;
+      pend.nact = nact;
+      pend.s_lo = s_lo;
+      pend.s_hi = s_hi;
+      pend.off = act_off;
+      pend.box = box;
+      if (launch_probe(c, set, act_off, nact, s_lo, s_hi, box, pend.slot, sc, ss, multi)) return 1;
     }
+    for (int b = 0; b < nb; b++) batch_cells += run[b].nbox > 0 ? box_cells(round_box(reach, run[b].nbox)) : 0;
     // final sub-boxes for the rates launch
     for (int b = 0; b < nb; b++) {
       SrcDev &S = c->h_src[set][b];

@@ -19,18 +19,19 @@ def main():
     rows = []
     for r in csv.DictReader(open(a.csv)):
         n = r["Kernel_Name"]
-        kind = next((k for k in ("k_sweep_shell", "k_sweep_core", "k_loss_finish", "k_loss_exact", "k_rates", "k_chemistry", "k_transpose_ij") if k in n), None)
+        kind = next((k for k in ("k_sweep_shell", "k_sweep_core", "k_loss_finish", "k_loss", "k_rates", "k_chemistry", "k_transpose_ij") if k in n), None)
         if kind:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, int(r["Grid_Size_X"]), int(r["Grid_Size_Y"])))
     rows.sort()
     # passes: runs of sweep/loss launches between two k_rates launches; take the last complete one
+    # a pass starts with k_transpose_ij; the rates and chemistry launches are listed but not part of the sweep
     passes, cur = [], []
     for row in rows:
-        if row[2] in ("k_rates", "k_chemistry", "k_transpose_ij"):
+        if row[2] == "k_transpose_ij":
             if cur:
                 passes.append(cur)
             cur = []
-        else:
+        elif row[2] != "k_chemistry":
             cur.append(row)
     if cur:
         passes.append(cur)
@@ -49,6 +50,8 @@ def main():
         busy += e - s
         rate = ""
         sh = ""
+        if kind == "k_rates":
+            busy -= e - s
         if kind.startswith("k_sweep"):
             cells = 1 if shell == 0 else 24 * shell * shell + 2
             rate = f"{88.0 * cells * gy / (e - s):10.1f}"
