@@ -1067,6 +1067,9 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   if (!out || !mesh) return fail(nullptr, "c2r_create: null argument");
   if (mesh[0] < 2 || mesh[1] < 2 || mesh[2] < 2 || mesh[0] > 4096 || mesh[1] > 4096 || mesh[2] > 4096)
     return fail(nullptr, "c2r_create: mesh %d x %d x %d out of range [2,4096]", mesh[0], mesh[1], mesh[2]);
+  // cell numbers travel as 32-bit integers through the tile lists and the chemistry's lists of deferred cells
+  if ((double)mesh[0] * mesh[1] * mesh[2] >= 2147483648.0)
+    return fail(nullptr, "c2r_create: mesh %d x %d x %d has 2^31 cells or more (the largest cube is 1290^3)", mesh[0], mesh[1], mesh[2]);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
