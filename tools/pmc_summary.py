@@ -10,7 +10,7 @@ import sys
 
 
 def kname(n):
-    for k in ("k_rates", "k_chemistry", "k_sweep_shell", "k_loss_finish", "k_loss_exact", "k_transpose_ij"):
+    for k in ("k_rates", "k_chemistry", "k_sweep_shell", "k_loss_finish", "k_loss_probe", "k_loss", "k_transpose_ij"):
         if k in n:
             return k
     return None
