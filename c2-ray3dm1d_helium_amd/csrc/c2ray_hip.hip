@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +49,7 @@ struct SrcDev {
   int lo[3], hi[3];    // FINAL sub-box as offsets last_l - srcpos, last_r - srcpos (set before the rates launch)
   double nflux;        // NormFlux(ns)
   double nflux_sed[2]; // NormFluxPL(ns), NormFluxQPL(ns) (-DPL / -DQUASARS builds), else 0
-  size_t col;          // first double of this source's column block in the scratch arena
+  double *cols;        // this source's column block in the scratch arena
   size_t cz;           // entries per column array of that block: (2*cap+1)^3, cap = shells the block can hold
 };
 // the sub-box of the round in flight: the same for every active source of a batch (all are in the same round)
@@ -187,7 +188,7 @@ k_transpose_ij(Grid g, Ptr4 P) {
 // last shell of every round took twice as long as its neighbours.  Here every lane of every wave has a cell.)
 __global__ void __launch_bounds__(BLOCK)
 k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int multi, int s_lo, int s_hi, Box box,
-       StepScalars sc, const double *__restrict__ arena, const BandData *__restrict__ bd, SedSet ss,
+       StepScalars sc, const BandData *__restrict__ bd, SedSet ss,
        const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
   __shared__ double sh[BLOCK / 64];
   const SrcDev &S = src[list[blockIdx.y]];
@@ -211,7 +212,7 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
     if (inside && boundary) {
       const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      const double *cs = arena + S.col;
+      const double *cs = S.cols;
       const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
       const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
       if (cin_HI < max_coldensh) {
@@ -249,7 +250,7 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
 // is replaced by the full sum of k_loss.  No bit of any result depends on this kernel.
 __global__ void __launch_bounds__(BLOCK)
 k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int multi, int s_lo, int s_hi, Box box,
-             StepScalars sc, const double *__restrict__ arena, const BandData *__restrict__ bd, SedSet ss,
+             StepScalars sc, const BandData *__restrict__ bd, SedSet ss,
              const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
   __shared__ double sh[BLOCK / 64];
   const SrcDev &S = src[list[blockIdx.y]];
@@ -274,7 +275,7 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
     if (inside && boundary) {
       const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      const double *cs = arena + S.col;
+      const double *cs = S.cols;
       const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
       const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
       if (cin_HI < max_coldensh) {
@@ -313,7 +314,7 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
 __global__ void __launch_bounds__(BLOCK)
 k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ active, int shell, Box box, StepScalars sc,
               const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
-              const double *__restrict__ stateT, double *__restrict__ arena, const float *__restrict__ lls_grid) {
+              const double *__restrict__ stateT, const float *__restrict__ lls_grid) {
   const SrcDev &S = src[active[blockIdx.y]];
   const long long cnt = shell_count(shell);
   // Which 256 cells of the shell this block takes.  Blocks are dealt round-robin over the 8 XCDs, each with its
@@ -337,7 +338,7 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
   if (!inside) return;
   const size_t nc = g.ncell, cz = S.cz;
   const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-  double *cs = arena + S.col;
+  double *cs = S.cols;
   double nd, h0, he0, he1;
   const int w_ = 2 * shell + 1;
   if (shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
@@ -425,7 +426,7 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
 template <bool HEAT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? 4 : 4) : (HEAT ? 4 : C2R_RATES_WAVES_ISO))
 k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const double *__restrict__ ndens,
-        const double *__restrict__ xh_av, const double *__restrict__ xhe_av, const double *__restrict__ arena,
+        const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
         const BandData *__restrict__ bd, SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles,
         const int *__restrict__ tile_ptr, const int *__restrict__ tile_src, int tile_base) {
   const size_t nc = g.ncell;
@@ -479,7 +480,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     touched = true;
     const size_t cz = S.cz;
     const size_t p = shell_position(di, dj, dk);
-    const double *cs = arena + S.col;
+    const double *cs = S.cols;
     const double cout_HI = cs[p + 3 * cz];
     const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
     const double cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
@@ -894,13 +895,17 @@ struct c2r_ctx {
   size_t rates_count = 0;
 
   int batch = 256;                 // most sources per batch (c2r_set_batch); the scratch arena may allow fewer
-  // Column scratch: one arena of two halves (ping-pong sets); a source's block holds the shells it is expected
-  // to need (shell-ordered arrays are prefixes of one another, so a block that turns out too small moves by
-  // six copies).  Zeroed at allocation and only ever holding finite columns afterwards.
-  double *d_arena = nullptr;
-  size_t arena_half = 0;           // doubles per half
-  size_t arena_half_prev = 0;      // before the last growth
-  size_t arena_used[2] = {0, 0};
+  // Column scratch: per ping-pong set a list of segments; a source's block is cut from the current segment of
+  // its set (shell-ordered arrays are prefixes of one another, so a block that turns out too small moves to a
+  // deeper one by six copies).  A set that runs out of room gets another segment -- nothing that exists moves, no
+  // sweep starts over.  Segments are zeroed when allocated and only ever hold finite columns afterwards.
+  struct Segment {
+    double *p = nullptr;
+    size_t n = 0; // doubles
+  };
+  std::vector<Segment> segs[2];
+  size_t seg_cur[2] = {0, 0}, seg_used[2] = {0, 0}; // bump allocation within a batch
+  size_t arena_total = 0;                          // doubles in all segments
   std::vector<int> prev_nbox;      // per source: sub-boxes of the last pass (0: unknown), sizes the next block
   SrcDev *d_src[2] = {nullptr, nullptr}, *h_src[2] = {nullptr, nullptr}; // source records of the two sets (h: pinned)
   int *d_list[2] = {nullptr, nullptr}, *h_list[2] = {nullptr, nullptr};  // active lists of a batch's rounds, one after another
@@ -930,7 +935,8 @@ struct c2r_ctx {
   int *d_conv = nullptr;
   int *h_conv = nullptr;    // pinned
   int last_src = 0;
-  size_t last_col = 0, last_cz = 0; // column block of the last source swept (c2r_download_columns)
+  double *last_cols = nullptr;      // column block of the last source swept (c2r_download_columns)
+  size_t last_cz = 0;
   int last_lo[3] = {0, 0, 0}, last_hi[3] = {0, 0, 0};
 
   double photon_loss[C2R_NFREQ] = {0};
@@ -1016,37 +1022,43 @@ static size_t block_doubles(int cap) { // doubles of a column block that holds s
   return 6 * w * w * w;
 }
 
-// The arena holds at least `need_half` doubles per half afterwards (or the call fails).  Growing means a new
-// allocation: nothing may be in flight, and the columns of both sets are lost (callers restart their batch).
-static int ensure_arena(c2r_ctx *c, size_t need_half, bool *grown) {
-  if (grown) *grown = false;
-  if (c->d_arena && c->arena_half >= need_half) return 0;
-  // what could be had: 80 % of the memory that is free once the present arena is given back.  Decided BEFORE
-  // anything is freed: a request that cannot be met leaves the arena as it is (the caller shrinks its batch).
-  size_t free_b = 0, total_b = 0;
-  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-  const size_t have_b = c->d_arena ? sizeof(double) * 2 * c->arena_half : 0;
-  const size_t limit = (size_t)(0.8 * (double)(free_b + have_b)) / (2 * sizeof(double));
-  if (need_half > limit)
-    return fail(c, "column scratch: two halves of %.1f GB do not fit in %.1f GB of free device memory", need_half * 8e-9,
-                (free_b + have_b) / 1e9);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream2));
-  if (c->d_arena) HIPCHK(c, hipFree(c->d_arena));
-  c->d_arena = nullptr;
-  c->arena_half_prev = c->arena_half;
-  c->arena_half = 0;
-  // grows geometrically (an allocation of tens of GB takes of the order of a second): at least twice what
-  // there was and twice what is asked for now, within the limit
-  size_t want = std::min(limit, std::max(std::max(2 * need_half, 2 * c->arena_half_prev), (size_t)1 << 28));
-  HIPCHK(c, hipMalloc(&c->d_arena, sizeof(double) * 2 * want));
-  HIPCHK(c, zero_device(c->d_arena, sizeof(double) * 2 * want, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->arena_half = want;
-  c->arena_used[0] = c->arena_used[1] = 0;
-  c->set_busy[0] = c->set_busy[1] = false;
-  if (grown) *grown = true;
-  return 0;
+// `n` doubles for a column block of set `set`, or nullptr when the device has no room for another segment (the
+// caller then shrinks its batch).  Blocks are cut from the set's segments one after another; a new segment is at
+// least half of what the set has so far (and 2 GB), so that their number stays small: hipMalloc costs ~25 ms
+// per GB on this system, which is why nothing is allocated ahead of need.
+static double *arena_alloc(c2r_ctx *c, int set, size_t n) {
+  for (;;) {
+    if (c->seg_cur[set] < c->segs[set].size()) {
+      c2r_ctx::Segment &sg = c->segs[set][c->seg_cur[set]];
+      if (c->seg_used[set] + n <= sg.n) {
+        double *p = sg.p + c->seg_used[set];
+        c->seg_used[set] += n;
+        return p;
+      }
+      c->seg_cur[set]++; // the rest of this segment stays unused in this batch
+      c->seg_used[set] = 0;
+      continue;
+    }
+    size_t have = 0;
+    for (const c2r_ctx::Segment &sg : c->segs[set]) have += sg.n;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return nullptr;
+    const size_t room = (size_t)(0.9 * (double)free_b) / sizeof(double);
+    if (n > room) return nullptr;
+    const size_t want = std::min(room, std::max(n, std::max(have / 2, (size_t)1 << 28)));
+    c2r_ctx::Segment sg;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (hipMalloc(&sg.p, sizeof(double) * want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    sg.n = want;
+    // zeroed on the sweep stream: whatever uses the block is queued behind it there
+    if (zero_device(sg.p, sizeof(double) * want, c->stream) != hipSuccess) { (void)hipFree(sg.p); return nullptr; }
+    if (getenv("C2R_ARENA_LOG"))
+      fprintf(stderr, "c2ray_hip: column scratch, set %d: segment %zu of %.2f GB (%.0f ms), %.2f GB in all\n", set,
+              c->segs[set].size(), want * 8e-9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+              (c->arena_total + want) * 8e-9);
+    c->segs[set].push_back(sg);
+    c->arena_total += want;
+  }
 }
 
 template <class T>
@@ -1175,9 +1187,12 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_stateT, c->d_arena, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl};
+                  c->d_rates_own, c->d_stateT, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto &list : c->segs)
+    for (auto &sg : list)
+      if (sg.p) (void)hipFree(sg.p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->h_probe) (void)hipHostFree(c->h_probe);
   for (int k = 0; k < 2; k++) {
@@ -1721,7 +1736,7 @@ static int boundary_loss(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, 
     if (ensure_pair<double>(c, &c->d_loss_partial, (double **)nullptr, &c->loss_partial_cap, need)) return 1;
   }
   hipLaunchKernelGGL(k_loss, dim3(nblk, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
-                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_arena, c->d_bands, ss, c->d_block_base, c->d_loss_partial, nblk,
+                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_bands, ss, c->d_block_base, c->d_loss_partial, nblk,
                      sample);
   hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, nblk, nblk, c->d_loss_acc);
   c->tm.sweep_launches += 2;
@@ -1745,7 +1760,7 @@ static int launch_probe(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, i
     if (ensure_pair<double>(c, &c->d_probe_partial[slot], (double **)nullptr, &c->probe_partial_cap[slot], need)) return 1;
   }
   hipLaunchKernelGGL(k_loss_probe, dim3(nblk, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
-                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_arena, c->d_bands, ss, c->d_block_base, c->d_probe_partial[slot], nblk,
+                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_bands, ss, c->d_block_base, c->d_probe_partial[slot], nblk,
                      PROBE_SAMPLE);
   hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, c->stream, c->d_probe_partial[slot], nblk, nblk,
                      c->d_probe_acc + (size_t)slot * BATCH_MAX);
@@ -1824,30 +1839,29 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       HIPCHK(c, hipEventSynchronize(c->ev_rates_done[set]));
     }
     std::vector<SrcRun> run;
-    bool full_caps = false; // after the arena ran out mid-sweep: blocks for the whole mesh, fewer sources
   restart_batch:
     run.assign((size_t)nb, SrcRun());
     {
-      // blocks of this batch; when they do not fit, the arena grows (up to 80 % of the free memory), and when
-      // that is not enough the batch shrinks
+      // blocks of this batch; when the device has no room for them the batch shrinks
       for (;;) {
-        size_t need = 0;
-        for (int b = 0; b < nb; b++) {
-          run[b].ns = mine[b0 + b];
-          run[b].cap = full_caps ? g.smax : predicted_cap(run[b].ns);
-          need += block_doubles(run[b].cap);
+        c->seg_cur[set] = 0;
+        c->seg_used[set] = 0;
+        SrcDev *hs = c->h_src[set];
+        bool fits = true;
+        for (int b = 0; b < nb && fits; b++) {
+          SrcRun &r = run[b];
+          r.ns = mine[b0 + b];
+          r.cap = predicted_cap(r.ns);
+          const size_t w = (size_t)(2 * r.cap + 1);
+          hs[b].cz = w * w * w;
+          hs[b].cols = arena_alloc(c, set, 6 * hs[b].cz);
+          fits = hs[b].cols != nullptr;
         }
-        // room for one source to move into a block for the whole mesh without a restart
-        if (!full_caps) need += block_doubles(g.smax);
-        if (need <= c->arena_half) break;
-        const std::string saved = c->err; // a failed growth is not an error yet: the batch shrinks first
-        if (ensure_arena(c, need, nullptr) == 0) break;
-        c->err = saved;
-        if (nb == 1 && full_caps) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
-        if (nb > 1) nb = (nb + 1) / 2; else full_caps = true;
+        if (fits) break;
+        if (nb == 1) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
+        nb = (nb + 1) / 2;
         run.resize((size_t)nb);
       }
-      c->arena_used[set] = 0;
       SrcDev *hs = c->h_src[set];
       for (int b = 0; b < nb; b++) {
         SrcRun &r = run[b];
@@ -1862,10 +1876,6 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         for (int d = 0; d < 3; d++) { S.lo[d] = 0; S.hi[d] = 0; }
         S.nflux = c->normflux[r.ns - 1];
         for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][r.ns - 1];
-        S.col = (size_t)set * c->arena_half + c->arena_used[set];
-        const size_t w = (size_t)(2 * r.cap + 1);
-        S.cz = w * w * w;
-        c->arena_used[set] += 6 * S.cz;
       }
       HIPCHK(c, hipMemcpyAsync(c->d_src[set], hs, sizeof(SrcDev) * nb, hipMemcpyHostToDevice, c->stream));
     }
@@ -1962,28 +1972,29 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         if (r.cap >= s_hi) continue;
         const int ncap = std::min(g.smax, std::max(s_hi, 2 * r.cap));
         const size_t nd = block_doubles(ncap);
-        if (c->arena_used[set] + nd > c->arena_half) {
-          // Out of room in the middle of a sweep.  Nothing of this batch has reached the rate grids yet, so the
-          // batch starts over with what this attempt has taught: sources that have stopped get the block they
-          // needed, those still growing twice the rounds they have come to (the sizing loop then grows the
-          // arena, or shrinks the batch).  Each restart at least doubles the blocks of the growing sources.
+        double *ncols = arena_alloc(c, set, nd);
+        if (!ncols) {
+          // No room left on the device in the middle of a sweep.  Nothing of this batch has reached the rate
+          // grids yet, so the batch starts over with what this attempt has taught (sources that have stopped get
+          // the block they needed, those still growing two rounds more than they have come to) and, since even
+          // that did not fit, with fewer sources.
           HIPCHK(c, hipStreamSynchronize(c->stream));
           for (int b = 0; b < nb; b++) {
             int &pn = c->prev_nbox[(size_t)run[b].ns - 1];
-            pn = std::max(pn, run[b].active ? 2 * run[b].nbox : run[b].nbox);
+            pn = std::max(pn, run[b].active ? run[b].nbox + 2 : run[b].nbox);
           }
+          if (nb == 1) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
+          nb = (nb + 1) / 2;
           goto restart_batch;
         }
         SrcDev &S = c->h_src[set][act[a]];
-        const size_t ncol = (size_t)set * c->arena_half + c->arena_used[set];
         const size_t wn = (size_t)(2 * ncap + 1), ncz = wn * wn * wn;
         const size_t wp = (size_t)(2 * r.smax_prev + 1), have = r.smax_prev >= 0 ? wp * wp * wp : 0;
         for (int k = 0; k < 6 && have > 0; k++)
-          HIPCHK(c, hipMemcpyAsync(c->d_arena + ncol + (size_t)k * ncz, c->d_arena + S.col + (size_t)k * S.cz, sizeof(double) * have,
+          HIPCHK(c, hipMemcpyAsync(ncols + (size_t)k * ncz, S.cols + (size_t)k * S.cz, sizeof(double) * have,
                                    hipMemcpyDeviceToDevice, c->stream));
-        S.col = ncol;
+        S.cols = ncols;
         S.cz = ncz;
-        c->arena_used[set] += nd;
         r.cap = ncap;
         HIPCHK(c, hipMemcpyAsync(c->d_src[set] + act[a], &S, sizeof(SrcDev), hipMemcpyHostToDevice, c->stream));
       }
@@ -2002,7 +2013,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
         const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
         hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + act_off,
-                           s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stateT, c->d_arena,
+                           s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stateT,
                            c->lls_on_grid ? c->d_lls : nullptr);
         c->tm.sweep_launches++;
       }
@@ -2130,7 +2141,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     }
 #define C2R_LAUNCH_RATES(H, M)                                                                               \
   hipLaunchKernelGGL((k_rates<H, M>), dim3(cnt_), dim3(BLOCK), 0, st_, g, c->d_src[set], nb, sc, c->d_ndens, c->d_xh_av, \
-                     c->d_xhe_av, c->d_arena, c->d_bands, ss, c->d_rates, d_tiles, d_tptr, d_tsrc, base_)
+                     c->d_xhe_av, c->d_bands, ss, c->d_rates, d_tiles, d_tptr, d_tsrc, base_)
     const bool last_batch = b0 + nb >= mine.size();
     const int pieces = (last_batch && ns_eff > 0) ? ns_eff : 1;
     const int per_layer = nt1 * nt2;
@@ -2206,7 +2217,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     }
     c->tm.cells_swept += batch_cells;
     c->last_src = run[nb - 1].ns;
-    c->last_col = c->h_src[set][nb - 1].col;
+    c->last_cols = c->h_src[set][nb - 1].cols;
     c->last_cz = c->h_src[set][nb - 1].cz;
     {
       const SrcDev &S = c->h_src[set][nb - 1];
@@ -2546,7 +2557,7 @@ static int upload_iter_state_one(c2r_ctx *c, const double *xh_av, const double *
 
 extern "C" int c2r_download_columns(c2r_ctx *c, double *coldensh_out, double *coldenshe_out) {
   if (!c) return 1;
-  if (!c->d_arena || c->last_src < 1) return fail(c, "c2r_download_columns: no source has been swept yet");
+  if (!c->last_cols || c->last_src < 1) return fail(c, "c2r_download_columns: no source has been swept yet");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
   if (!c->d_colgrid) HIPCHK(c, hipMalloc(&c->d_colgrid, sizeof(double) * 3 * nc));
@@ -2556,7 +2567,7 @@ extern "C" int c2r_download_columns(c2r_ctx *c, double *coldensh_out, double *co
   S.i0 = p[0]; S.j0 = p[1]; S.k0 = p[2];
   for (int d = 0; d < 3; d++) { S.lo[d] = c->last_lo[d]; S.hi[d] = c->last_hi[d]; }
   S.cz = c->last_cz;
-  hipLaunchKernelGGL(k_col_to_grid, dim3(nblk), dim3(BLOCK), 0, c->stream, c->g, S, c->d_arena + c->last_col, c->d_colgrid);
+  hipLaunchKernelGGL(k_col_to_grid, dim3(nblk), dim3(BLOCK), 0, c->stream, c->g, S, c->last_cols, c->d_colgrid);
   HIPCHK(c, hipGetLastError());
   if (coldensh_out) HIPCHK(c, hipMemcpyAsync(coldensh_out, c->d_colgrid, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
   if (coldenshe_out)
