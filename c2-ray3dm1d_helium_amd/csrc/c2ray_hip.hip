@@ -423,8 +423,17 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
 #ifndef C2R_RATES_WAVES_ISO
 #define C2R_RATES_WAVES_ISO 5
 #endif
+// Waves per SIMD the register allocation aims at.  The kernel is bound by instruction issue at any of these
+// occupancies, so the setting only steers how many copies and spills the allocator makes; measured per variant
+// (heating, one SED: 33.2 / 32.6 / 32.7 ms at 4 / 3 / 2 waves; heating, three SEDs: 443 / 466 / 425 ms).
+#ifndef C2R_RATES_WAVES_HEAT
+#define C2R_RATES_WAVES_HEAT 3
+#endif
+#ifndef C2R_RATES_WAVES_HEAT_MULTI
+#define C2R_RATES_WAVES_HEAT_MULTI 2
+#endif
 template <bool HEAT, bool MULTI>
-__global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? 4 : 4) : (HEAT ? 4 : C2R_RATES_WAVES_ISO))
+__global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? C2R_RATES_WAVES_HEAT_MULTI : 4) : (HEAT ? C2R_RATES_WAVES_HEAT : C2R_RATES_WAVES_ISO))
 k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const double *__restrict__ ndens,
         const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
         const BandData *__restrict__ bd, SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles,
