@@ -574,18 +574,18 @@ def _pass_result(pkg, tables, mat, grid, src, cosmo, n, batch, first=1, stride=1
 def test_many_faint_sources_batch_invariance_256(pkg, tables):
     """BASELINE configs[3]-like: 256^3 log-normal density, 1024 seeded sources of 1e52..1e54 photons/s in
     neutral gas, the 128 sources of rank 0 of 8.  Sub-boxes stop early (5-6 rounds), so the rates launches
-    run on host-built tile lists.  Batches of 4 and of 16 sources (scratch of 6.5 and 26 GB: the second is
-    beyond the 16 GiB a single hipMemset handled) must give identical bits."""
+    run on host-built tile lists.  Batches of 4, of 16 and of all 128 sources must give identical bits."""
     import sys
     sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
     import bench_config4
     n = 256
     mat, grid, src, cosmo = bench_config4.config4_inputs(pkg, n, 1024)
     a = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 4, 1, 8)
-    b = _pass_result(pkg, tables, mat, grid, src, cosmo, n, 16, 1, 8)
-    for x, y in zip(a, b):
-        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
-        assert x[2:] == y[2:]
+    for batch in (16, 128):   # 128: the whole rank share in one batch (column blocks from the arena, per-tile source lists)
+        b = _pass_result(pkg, tables, mat, grid, src, cosmo, n, batch, 1, 8)
+        for x, y in zip(a, b):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), batch
+            assert x[2:] == y[2:], batch
     assert 128 * 3 < a[0][3] < 128 * 13 and a[0][4] > 0          # boxes really stopped early
 
 
