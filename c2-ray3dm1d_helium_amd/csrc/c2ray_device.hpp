@@ -405,6 +405,39 @@ C2R_HD bool thermal(const CoolData &cd, double dt, double &end_temper, double &a
   return false;
 }
 
+// true if the predicate holds in any lane of the wave (on the host: for this one evaluation)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool any_lane(bool p) { return __any(p ? 1 : 0) != 0; }
+#else
+inline bool any_lane(bool p) { return p; }
+#endif
+
+// Diagnostic build only (-DC2R_RATES_COUNT, tools/bench_config4.py --lane-census): how well the lanes of a wave
+// are used by the band loop.  [0] band bodies a wave ran, [1] lanes alive in them, [2] bands skipped by the
+// whole wave, [3] source bodies a wave ran, [4] lanes inside the sub-box in them, [5] sources skipped by the wave;
+// [6..8] the same triple for div_by_vol's doubt branch, [9..11] for its true divisions, [12..14] for the near-1 path
+// of the log.
+#if defined(C2R_RATES_COUNT)
+extern __device__ unsigned long long c2r_rates_cnt[64 * 24];
+#endif
+#if defined(C2R_RATES_COUNT) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void count_lanes(int what, bool alive) {
+  const unsigned long long here = __ballot(1), m = __ballot(alive ? 1 : 0);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)here) - 1) {
+    unsigned long long *c = c2r_rates_cnt + (blockIdx.x & 63) * 24;
+    if (m) {
+      atomicAdd(c + what, 1ull);
+      atomicAdd(c + what + 1, (unsigned long long)__popcll(m));
+    } else {
+      atomicAdd(c + what + 2, 1ull);
+    }
+  }
+}
+#define C2R_COUNT_LANES(what, alive) count_lanes(what, alive)
+#else
+#define C2R_COUNT_LANES(what, alive) ((void)0)
+#endif
+
 // ----------------------------------------------------------------------------------------
 // radiation_photoionrates.f90: table position of one optical depth (:282-306)
 struct TauPos {
@@ -451,6 +484,9 @@ C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab
   const gm::Log10Arg a = gm::log10_split(dmax_num(tau_a, 1.0e-20)), b = gm::log10_split(dmax_num(tau_b, 1.0e-20));
   double lga = gm::log_table_path(a, logtab), lgb = gm::log_table_path(b, logtab);
   const bool na = gm::log10_near1(a), nb = gm::log10_near1(b);
+  C2R_COUNT_LANES(12, na || nb);
+  C2R_COUNT_LANES(15, na && nb);
+  C2R_COUNT_LANES(18, any_lane(na) && any_lane(nb));
   if (na || nb) {
     if (na) lga = gm::log_near1(gm::log10_arg_value(a));
     if (nb) lgb = gm::log_near1(gm::log10_arg_value(b));
@@ -559,10 +595,12 @@ C2R_HD void div_by_vol(const Recip &R, const double (&a)[N], double (&d)[N]) {
     d[n] = __builtin_fma(__builtin_fma(-R.b, q[n], a[n]), R.y, q[n]);
     doubt = doubt || !(fabs(q[n]) >= 0x1p-900);
   }
+  C2R_COUNT_LANES(6, doubt);
   if (doubt) {
     bool redo = !R.ok_big;
 #pragma unroll
     for (int n = 0; n < N; n++) redo = redo || (!(fabs(q[n]) >= 0x1p-900) && a[n] != 0.0);
+    C2R_COUNT_LANES(9, redo);
     if (redo) {
 #pragma unroll
       for (int n = 0; n < N; n++) d[n] = a[n] / R.b;
@@ -751,12 +789,7 @@ C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const doub
   return false;
 }
 
-// true if the predicate holds in any lane of the wave (on the host: for this one evaluation)
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ bool any_lane(bool p) { return __any(p ? 1 : 0) != 0; }
-#else
-inline bool any_lane(bool p) { return p; }
-#endif
+
 
 // what one photo_lookuptable + heat_lookuptable pair of calls returns for one SED (before the sums of
 // radiation_photoionrates.f90:178-262 put them together)
@@ -791,14 +824,23 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
   const int e0 = bhi < NB1 ? bhi : NB1, e1 = bhi < NB1 + NB2 ? bhi : NB1 + NB2;
   int b = blo;
   bool look = true;
-  for (; b < e0; b++)
-    look = any_lane(band_rates<HEAT, 0>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o));
+  for (; b < e0; b++) {
+    const bool dead = band_rates<HEAT, 0>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
+    C2R_COUNT_LANES(0, !dead);
+    look = any_lane(dead);
+  }
   look = true;
-  for (; b < e1; b++)
-    look = any_lane(band_rates<HEAT, 1>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o));
+  for (; b < e1; b++) {
+    const bool dead = band_rates<HEAT, 1>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
+    C2R_COUNT_LANES(0, !dead);
+    look = any_lane(dead);
+  }
   look = true;
-  for (; b < bhi; b++)
-    look = any_lane(band_rates<HEAT, 2>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o));
+  for (; b < bhi; b++) {
+    const bool dead = band_rates<HEAT, 2>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
+    C2R_COUNT_LANES(0, !dead);
+    look = any_lane(dead);
+  }
   out.photo_HI = o.photo_HI;
   out.photo_HeI = o.photo_HeI;
   out.photo_HeII = o.photo_HeII;

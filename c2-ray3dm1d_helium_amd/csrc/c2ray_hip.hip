@@ -492,7 +492,9 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     // Cells outside the source's last sub-box were never traced (evolve_source.F90:136-144): no
     // contribution.  (The reference's own marker is coldensh_out == 0, evolve_point.F90:120; every cell
     // of the box is traced exactly once, so "inside the box" is the same set and needs no zeroing.)
-    if (di < S.lo[0] || di > S.hi[0] || dj < S.lo[1] || dj > S.hi[1] || dk < S.lo[2] || dk > S.hi[2]) continue;
+    const bool outside = di < S.lo[0] || di > S.hi[0] || dj < S.lo[1] || dj > S.hi[1] || dk < S.lo[2] || dk > S.hi[2];
+    C2R_COUNT_LANES(3, !outside);
+    if (outside) continue;
     touched = true;
     const size_t cz = S.cz;
     const size_t p = shell_position(di, dj, dk);
@@ -2850,4 +2852,21 @@ extern "C" int c2r_synchronize(c2r_ctx *c) {
   return for_replicas(c, [&](c2r_ctx *r) { return synchronize_one(r); });
 }
 
+#ifdef C2R_RATES_COUNT
+// diagnostic build only: see count_lanes (c2ray_device.hpp)
+__device__ unsigned long long c2r::c2r_rates_cnt[64 * 24];
+extern "C" int c2r_debug_rates_counters(unsigned long long out[24], int reset) {
+  unsigned long long h[64 * 24];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(c2r::c2r_rates_cnt), sizeof(h)) != hipSuccess) return 1;
+  for (int k = 0; k < 24; k++) {
+    out[k] = 0;
+    for (int s = 0; s < 64; s++) out[k] += h[s * 24 + k];
+  }
+  if (reset) {
+    memset(h, 0, sizeof(h));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c2r::c2r_rates_cnt), h, sizeof(h)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 #include "c2ray_comm.inc"

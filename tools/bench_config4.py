@@ -50,6 +50,22 @@ def config4_inputs(pkg, n=256, nsrc=1024, seed=2024, heating=False):
     return mat, grid, src, cosmo
 
 
+def lane_census(pkg):
+    """Counters of the -DC2R_RATES_COUNT build (c2ray_device.hpp count_lanes), read and reset."""
+    import ctypes
+    lib = pkg._lib.load()
+    out = (ctypes.c_ulonglong * 24)()
+    if lib.c2r_debug_rates_counters(out, 1) != 0:
+        raise RuntimeError("c2r_debug_rates_counters failed")
+    bands, lanes, skipped, srcs, inbox, srcskip = (int(out[k]) for k in range(6))
+    return {"band_bodies_per_wave": bands, "band_lane_fill": lanes / (64.0 * bands) if bands else None, "bands_skipped_by_wave": skipped,
+            "div_doubt_waves": int(out[6]), "div_doubt_lanes": int(out[7]), "div_no_doubt_waves": int(out[8]),
+            "div_redo_waves": int(out[9]), "div_redo_lanes": int(out[10]), "log_near1_waves": int(out[12]), "log_near1_lanes": int(out[13]),
+            "log_table_only_waves": int(out[14]),
+            "log_near1_both_args_waves": int(out[15]), "log_near1_both_args_lanes": int(out[16]), "log_near1_two_blocks_waves": int(out[18]),
+            "source_bodies_per_wave": srcs, "source_lane_fill": inbox / (64.0 * srcs) if srcs else None, "sources_skipped_by_wave": srcskip}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mesh", type=int, default=256)
@@ -62,6 +78,9 @@ def main():
     ap.add_argument("--heating", action="store_true")
     ap.add_argument("--config5", action="store_true")
     ap.add_argument("--pl", action="store_true", help="the SEDs, heating and device-built tables of --config5 at --mesh / --sources")
+    ap.add_argument("--headline", action="store_true", help="bench.py's workload instead (256^3, 8 bright sources, pre-ionised gas): for --lane-census")
+    ap.add_argument("--lane-census", action="store_true",
+                    help="library built with -DC2R_RATES_COUNT: per iteration, how well k_rates' band loop fills its lanes")
     a = ap.parse_args()
     pkg = ge.load_package()
     if a.config5:
@@ -69,7 +88,12 @@ def main():
     if a.config5 or a.pl:
         a.config5 = a.heating = True
     n = a.mesh
-    mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating)
+    if a.headline:
+        import bench
+        a.sources, a.ranks, a.rank = 8, 1, 0
+        mat, grid, src, cosmo = bench.config3_inputs(pkg, n, 8, heating=a.heating)
+    else:
+        mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating)
     tables = pkg.RadiationTables.load()
     if a.config5:
         gold = ROOT / "tests" / "golden"
@@ -105,9 +129,12 @@ def main():
         conv = e.global_pass(dt)
         t2 = time.perf_counter()
         tm = e.timing()
+        census = lane_census(pkg) if a.lane_census else None
         hist.append({"iter": niter, "pass_ms": 1e3 * (t1 - t0), "chem_ms": 1e3 * (t2 - t1), "sweep_kernel_ms": tm.sweep_ms,
                      "rates_kernel_ms": tm.rates_ms, "cells_swept": int(tm.cells_swept), "sweep_launches": tm.sweep_launches,
                      "rates_launches": tm.rates_launches, "nonconv": int(conv), "sum_nbox": int(e.get_loss()[1])})
+        if census:
+            hist[-1]["lane_census"] = census
     wall = time.perf_counter() - t_all
     swept = sum(h["cells_swept"] for h in hist)
     out = {"tables_s": t_tab,
