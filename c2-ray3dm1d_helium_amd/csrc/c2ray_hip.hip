@@ -432,6 +432,9 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
 #ifndef C2R_RATES_WAVES_HEAT_MULTI
 #define C2R_RATES_WAVES_HEAT_MULTI 2
 #endif
+#ifndef C2R_RATES_XCD_CHUNK
+#define C2R_RATES_XCD_CHUNK 128
+#endif
 template <bool HEAT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? C2R_RATES_WAVES_HEAT_MULTI : 4) : (HEAT ? C2R_RATES_WAVES_HEAT : C2R_RATES_WAVES_ISO))
 k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const double *__restrict__ ndens,
@@ -456,7 +459,21 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   s_logtab[threadIdx.x] = gm::log_table()[threadIdx.x];
   __syncthreads();
   const int ti = (g.n1 + 7) >> 3, tj = (g.n2 + 7) >> 3;
-  const int tile = tiles ? tiles[tile_base + blockIdx.x] : tile_base + (int)blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin, and each XCD has its own L2.  A cube reads its columns as 32-byte
+  // rows of shell faces, so the other half of every cache line belongs to the neighbouring cube: give each XCD a
+  // contiguous run of tiles (a slab of the mesh), so that the neighbour's request finds the line in the same L2.
+  int vb = (int)blockIdx.x;
+#if C2R_RATES_XCD_CHUNK > 0
+  {
+    constexpr int C = C2R_RATES_XCD_CHUNK;
+    const int full = (int)(gridDim.x / (8 * C)) * (8 * C);
+    if (vb < full) {
+      const int r = vb >> 3, xcd = vb & 7;
+      vb = (r / C) * (8 * C) + xcd * C + (r % C);
+    }
+  }
+#endif
+  const int tile = tiles ? tiles[tile_base + vb] : tile_base + vb;
   const int bi = tile % ti, bj = (tile / ti) % tj, bk = tile / (ti * tj);
   const int lane = threadIdx.x & 63;
   const int w_ = threadIdx.x >> 6;
@@ -480,7 +497,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   Ricotti ric = {};
   if (HEAT) ric = ricotti_parameters(h1);
   bool touched = false;
-  const int slot = tile_base + (int)blockIdx.x;
+  const int slot = tile_base + vb;
   const int e0 = tile_ptr ? tile_ptr[slot] : 0, e1 = tile_ptr ? tile_ptr[slot + 1] : nsrc;
   for (int e = e0; e < e1; e++) {
     const SrcDev &S = src[tile_ptr ? tile_src[e] : e];
@@ -936,6 +953,8 @@ struct c2r_ctx {
   double *d_probe_partial[2] = {nullptr, nullptr}, *d_probe_acc = nullptr, *h_probe = nullptr;
   size_t probe_partial_cap[2] = {0, 0};
   hipEvent_t ev_probe[2] = {nullptr, nullptr};
+  hipEvent_t ev_round[2] = {nullptr, nullptr}; // the shells a probe looks at have been queued
+  hipStream_t stream_probe = nullptr;           // probes run beside the next round's shells
   // rates launches: listed tiles, and for each the sources that reach it (CSR), per set (h: pinned)
   int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr};
   int *d_tptr[2] = {nullptr, nullptr}, *h_tptr[2] = {nullptr, nullptr};
@@ -1132,6 +1151,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     CR(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
     CR(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
     CR(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo));
+    CR(hipStreamCreateWithPriority(&c->stream_probe, hipStreamNonBlocking, hi));
     CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   }
@@ -1182,6 +1202,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMalloc(&c->d_probe_acc, sizeof(double) * 2 * BATCH_MAX));
   CR(hipHostMalloc(&c->h_probe, sizeof(double) * 2 * BATCH_MAX));
   for (int k = 0; k < 2; k++) CR(hipEventCreateWithFlags(&c->ev_probe[k], hipEventDisableTiming));
+  for (int k = 0; k < 2; k++) CR(hipEventCreateWithFlags(&c->ev_round[k], hipEventDisableTiming));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
   CR(hipHostMalloc(&c->h_conv, sizeof(int)));
   CR(hipMalloc(&c->d_bands, sizeof(BandData)));
@@ -1218,6 +1239,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   for (int k = 0; k < 2; k++) {
     if (c->d_probe_partial[k]) (void)hipFree(c->d_probe_partial[k]);
     if (c->ev_probe[k]) (void)hipEventDestroy(c->ev_probe[k]);
+    if (c->ev_round[k]) (void)hipEventDestroy(c->ev_round[k]);
   }
   if (c->d_probe_acc) (void)hipFree(c->d_probe_acc);
   for (int k = 0; k < 2; k++) {
@@ -1240,6 +1262,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   }
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  if (c->stream_probe) { (void)hipStreamSynchronize(c->stream_probe); (void)hipStreamDestroy(c->stream_probe); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1781,26 +1804,37 @@ static int boundary_loss(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, 
 constexpr int PROBE_SAMPLE = 16; // the probe looks at 8 cells of every 16th block of the round's shells
 
 // Queue the probe of the round's loss for the sources d_list[set][list_off .. +n) into slot `slot` (results in
-// c->h_probe + slot * BATCH_MAX once c->ev_probe[slot] has happened).  Does not wait.
+// c->h_probe + slot * BATCH_MAX once c->ev_probe[slot] has happened).  Does not wait.  The probe runs on its own
+// stream behind the shells queued so far, so that the next round's shells (which only read what the probe reads)
+// need not queue behind its two small kernels and the copy of their result: ~22 us per round on the sweep stream.
+// Whoever then changes what a probe reads -- the SrcDev entries, when a block moves -- waits for ev_probe first.
 static int launch_probe(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, int s_hi, const Box &box, int slot,
                         const StepScalars &sc, const SedSet &ss, bool multi) {
   const int count = c->block_base[s_hi + 1] - c->block_base[s_lo];
   const int nblk = (count + PROBE_SAMPLE - 1) / PROBE_SAMPLE;
   const size_t need = (size_t)nblk * n;
   if (c->probe_partial_cap[slot] < need) {
+    HIPCHK(c, hipStreamSynchronize(c->stream_probe));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (ensure_pair<double>(c, &c->d_probe_partial[slot], (double **)nullptr, &c->probe_partial_cap[slot], need)) return 1;
   }
-  hipLaunchKernelGGL(k_loss_probe, dim3(nblk, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
+#ifdef C2R_PROBE_INLINE
+  hipStream_t st = c->stream;
+#else
+  hipStream_t st = c->stream_probe;
+  HIPCHK(c, hipEventRecord(c->ev_round[slot], c->stream));
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_round[slot], 0));
+#endif
+  hipLaunchKernelGGL(k_loss_probe, dim3(nblk, n), dim3(BLOCK), 0, st, c->g, c->d_src[set], c->d_list[set] + list_off,
                      multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_bands, ss, c->d_block_base, c->d_probe_partial[slot], nblk,
                      PROBE_SAMPLE);
-  hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, c->stream, c->d_probe_partial[slot], nblk, nblk,
+  hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, st, c->d_probe_partial[slot], nblk, nblk,
                      c->d_probe_acc + (size_t)slot * BATCH_MAX);
   c->tm.sweep_launches += 2;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->h_probe + (size_t)slot * BATCH_MAX, c->d_probe_acc + (size_t)slot * BATCH_MAX, sizeof(double) * n,
-                           hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev_probe[slot], c->stream));
+                           hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(c->ev_probe[slot], st));
   return 0;
 }
 
@@ -2014,6 +2048,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           // the block they needed, those still growing two rounds more than they have come to) and, since even
           // that did not fit, with fewer sources.
           HIPCHK(c, hipStreamSynchronize(c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream_probe));
           for (int b = 0; b < nb; b++) {
             int &pn = c->prev_nbox[(size_t)run[b].ns - 1];
             pn = std::max(pn, run[b].active ? run[b].nbox + 2 : run[b].nbox);
@@ -2022,6 +2057,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           nb = (nb + 1) / 2;
           goto restart_batch;
         }
+        // a probe in flight reads this source's SrcDev entry: it must be through before the entry changes
+        if (pend.on) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_probe[pend.slot], 0));
         SrcDev &S = c->h_src[set][act[a]];
         const size_t wn = (size_t)(2 * ncap + 1), ncz = wn * wn * wn;
         const size_t wp = (size_t)(2 * r.smax_prev + 1), have = r.smax_prev >= 0 ? wp * wp * wp : 0;
