@@ -341,8 +341,9 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
   double *cs = S.cols;
   double nd, h0, he0, he1;
   const int w_ = 2 * shell + 1;
-  if (shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
-    // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies
+  if (stateT && shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
+    // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies (not given for the inner
+    // shells, whose faces are small and which run while the copies are still being made)
     const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
     const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
     nd = stateT[qT];
@@ -558,8 +559,11 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
 #ifndef C2R_CHEM_BLOCK
 #define C2R_CHEM_BLOCK 64
 #endif
+#ifndef C2R_CHEM_WAVES
+#define C2R_CHEM_WAVES 2
+#endif
 template <bool HEAT>
-__global__ void __launch_bounds__(C2R_CHEM_BLOCK)
+__global__ void __launch_bounds__(C2R_CHEM_BLOCK, C2R_CHEM_WAVES)
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
@@ -986,6 +990,7 @@ struct c2r_ctx {
   hipStream_t stream2 = nullptr;
   hipStream_t stream3 = nullptr;    // takes every other slab of a cut rates launch (kernel tails overlap)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_transposed = nullptr; // the (j,i,k)-ordered state copies of this pass are complete
   hipEvent_t ev_sweep_done[2] = {nullptr, nullptr}, ev_rates_done[2] = {nullptr, nullptr};
   bool set_busy[2] = {false, false};
   std::vector<hipEvent_t> ev_pool; // timing events, grown on demand
@@ -1154,6 +1159,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     CR(hipStreamCreateWithPriority(&c->stream_probe, hipStreamNonBlocking, hi));
     CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    CR(hipEventCreateWithFlags(&c->ev_transposed, hipEventDisableTiming));
   }
   for (int i = 0; i < 2; i++) {
     CR(hipEventCreateWithFlags(&c->ev_sweep_done[i], hipEventDisableTiming));
@@ -1265,6 +1271,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   if (c->stream_probe) { (void)hipStreamSynchronize(c->stream_probe); (void)hipStreamDestroy(c->stream_probe); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_transposed) (void)hipEventDestroy(c->ev_transposed);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1801,6 +1808,12 @@ static int boundary_loss(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, 
   return 0;
 }
 
+// shells below this one read the i-faces' state from the mesh-ordered grids (see pass_list)
+#ifndef C2R_TRANSPOSED_FROM_SHELL
+#define C2R_TRANSPOSED_FROM_SHELL 32
+#endif
+constexpr int TRANSPOSED_FROM_SHELL = C2R_TRANSPOSED_FROM_SHELL;
+
 constexpr int PROBE_SAMPLE = 16; // the probe looks at 8 cells of every 16th block of the round's shells
 
 // Queue the probe of the round's loss for the sources d_list[set][list_off .. +n) into slot `slot` (results in
@@ -1873,13 +1886,17 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
 
   {
-    // (j,i,k)-ordered copies of the state the sweep reads (xh_av, xhe_av change every iteration)
+    // (j,i,k)-ordered copies of the state the sweep reads (xh_av, xhe_av change every iteration): made on the third
+    // stream while the inner shells, which do without them, are already on their way
     Ptr4 P;
     P.src[0] = c->d_ndens; P.src[1] = c->d_xh_av; P.src[2] = c->d_xhe_av; P.src[3] = c->d_xhe_av + nc;
     for (int a = 0; a < 4; a++) P.dst[a] = c->d_stateT + (size_t)a * nc;
-    hipLaunchKernelGGL(k_transpose_ij, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 4 * g.n3), dim3(BLOCK), 0, c->stream, g, P);
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_sweep_done[0], 0));
+    hipLaunchKernelGGL(k_transpose_ij, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 4 * g.n3), dim3(BLOCK), 0, c->stream3, g, P);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_transposed, c->stream3));
   }
+  bool transposed_seen = false; // the sweep stream has waited for ev_transposed
   // slabs: tile layers (4 planes each) [slab_layer[s], slab_layer[s+1])
   const int nt3_all = (g.n3 + 3) / 4;
   const int ns_eff = nslab > 0 ? std::min(nslab, nt3_all) : 0;
@@ -2081,11 +2098,15 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       cur_off = act_off;
       cur_nact = nact;
       for (int s = s_lo; s <= s_hi; s++) {
+        if (s >= TRANSPOSED_FROM_SHELL && !transposed_seen) {
+          HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_transposed, 0));
+          transposed_seen = true;
+        }
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
         const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
         hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + act_off,
-                           s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, c->d_stateT,
+                           s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, transposed_seen ? c->d_stateT : nullptr,
                            c->lls_on_grid ? c->d_lls : nullptr);
         c->tm.sweep_launches++;
       }
@@ -2129,6 +2150,12 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     }
     HIPCHK(c, hipMemcpyAsync(c->d_src[set], c->h_src[set], sizeof(SrcDev) * nb, hipMemcpyHostToDevice, c->stream));
     if (c->timing) HIPCHK(c, hipEventRecord(e_s1, c->stream));
+    if (!transposed_seen) {
+      // small boxes only: nobody needed the copies, but whatever follows this sweep (the global pass rewrites the
+      // state) has to come after the kernel that reads it
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_transposed, 0));
+      transposed_seen = true;
+    }
     HIPCHK(c, hipEventRecord(c->ev_sweep_done[set], c->stream));
 
     // rates of the whole batch, in source order, on the second stream
@@ -2316,6 +2343,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     }
     b0 += (size_t)nb;
   }
+  if (!transposed_seen) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_transposed, 0));
   // a rank without sources of its own still owes the caller its slab events
   if (mine.empty())
     for (int sidx = 0; sidx < ns_eff; sidx++) HIPCHK(c, hipEventRecord(c->ev_slab[sidx], c->stream2));
