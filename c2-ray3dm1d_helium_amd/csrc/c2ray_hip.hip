@@ -254,7 +254,10 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
              const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
   __shared__ double sh[BLOCK / 64];
   const SrcDev &S = src[list[blockIdx.y]];
-  const int B = block_base[s_lo] + (int)blockIdx.x * sample;
+  // every sample-th block counted from the END of the round: the surface of the box is mostly its outermost shell,
+  // and the last block of the round is always looked at (counted from the front, the 43 blocks of round 1 put
+  // blocks 0, 16 and 32 in shells 0, 7 and 9: no surface cell, no decision, the full sum every time)
+  const int B = block_base[s_hi + 1] - 1 - (int)blockIdx.x * sample;
   int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -2098,7 +2101,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       cur_off = act_off;
       cur_nact = nact;
       for (int s = s_lo; s <= s_hi; s++) {
-        if (s >= TRANSPOSED_FROM_SHELL && !transposed_seen) {
+        // (a large batch waits at once: its many small faces would pay more for strided reads than the wait costs)
+        if ((s >= TRANSPOSED_FROM_SHELL || nb > 16) && !transposed_seen) {
           HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_transposed, 0));
           transposed_seen = true;
         }
