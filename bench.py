@@ -42,8 +42,9 @@ PMC_SUMMARY = ROOT / "profiles" / "r02_bench_pmc_summary.json"
 
 def rates_bytes_per_launch(cells, nsrc, heating=False):
     """Compulsory HBM bytes of one k_rates launch over `nsrc` sources: the six columns of every cell.source,
-    and per cell the state (40 B) and the rate grids read and written once (3 or 4 grids)."""
-    return cells * (nsrc * 48.0 + 40.0 + (64.0 if heating else 48.0))
+    and per cell the state (40 B) and the rate grids written once (3 or 4 grids; the first launch of a pass that
+    covers every cell -- this workload's only one -- starts its sums from zero instead of reading them)."""
+    return cells * (nsrc * 48.0 + 40.0 + (32.0 if heating else 24.0))
 
 
 def stored_counter(kernel, counter):
@@ -186,6 +187,12 @@ def main():
                     help="config3 from the reference's neutral test-problem start (small sub-boxes, chemistry in its expensive state)")
     a = ap.parse_args()
 
+    # stdout carries ONE line, the result: whatever libraries print there while they start up (gloo, RCCL's version
+    # banner) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     pkg = ge.load_package()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -303,7 +310,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": stored_counter("k_rates", "hbm_bytes_per_launch_corrected") if headline else None,
                          "kernel": "k_rates",
-                         "note": "compulsory bytes of one k_rates launch (48 B of columns per cell.source + 88 B of state and "
+                         "note": "compulsory bytes of one k_rates launch (48 B of columns per cell.source + 64 B of state and "
                                  "rate grids per cell) / mean launch time (HIP events on the library's stream); traffic: stored "
                                  "rocprofv3 --pmc FETCH_SIZE (doubled, gfx950) + WRITE_SIZE of the same command (profiles/). The "
                                  "kernel is bound by FP64 instruction issue, see roofline_valu_issue"},
@@ -337,7 +344,8 @@ def main():
             ref = cpu_baseline_reference()
             if ref is not None:
                 out["cpu_baseline_reference"] = ref
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -448,9 +448,18 @@ struct TauPos {
 // max / min of two numbers neither of which is a NaN: one instruction
 C2R_HD double dmax_num(double a, double b) { return __builtin_fmax(a, b); }
 C2R_HD double dmin_num(double a, double b) { return __builtin_fmin(a, b); }
+// max(a, k) with the instruction spelled out: __builtin_fmax puts a canonicalising v_max_f64 a, a, a in front
+// whenever it cannot see where `a` was computed (another basic block); the operands here are results of
+// arithmetic, never signalling NaNs
+__device__ __forceinline__ double dmax_const(double a, double k) {
+  double d;
+  asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+  return d;
+}
 #else
 C2R_HD double dmax_num(double a, double b) { return a > b ? a : b; }
 C2R_HD double dmin_num(double a, double b) { return a < b ? a : b; }
+C2R_HD double dmax_const(double a, double k) { return a > k ? a : k; }
 #endif
 // the position that belongs to lt = log10(max(1e-20, tau))
 C2R_HD TauPos table_position_of_log(double lt) {
@@ -481,7 +490,7 @@ C2R_HD TauPos tau_table_position(double tau, const double *logtab = C2R_LOGTAB_D
 // straight line -- their loads and dependent fma chains overlap --, and the polynomial path of __log_fma
 // (arguments near 1: one in ten, spatially coherent) is entered only when some lane of the wave needs it.
 C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab, TauPos &pa, TauPos &pb) {
-  const gm::Log10Arg a = gm::log10_split(dmax_num(tau_a, 1.0e-20)), b = gm::log10_split(dmax_num(tau_b, 1.0e-20));
+  const gm::Log10Arg a = gm::log10_split(dmax_const(tau_a, 1.0e-20)), b = gm::log10_split(dmax_const(tau_b, 1.0e-20));
   double lga = gm::log_table_path(a, logtab), lgb = gm::log_table_path(b, logtab);
   const bool na = gm::log10_near1(a), nb = gm::log10_near1(b);
   C2R_COUNT_LANES(12, na || nb);

@@ -1072,8 +1072,9 @@ static size_t block_doubles(int cap) { // doubles of a column block that holds s
 // `n` doubles for a column block of set `set`, or nullptr when the device has no room for another segment (the
 // caller then shrinks its batch).  Blocks are cut from the set's segments one after another; a new segment is at
 // least half of what the set has so far (and 2 GB), so that their number stays small: hipMalloc costs ~25 ms
-// per GB on this system, which is why nothing is allocated ahead of need.
-static double *arena_alloc(c2r_ctx *c, int set, size_t n) {
+// per GB on this system, which is why nothing is allocated ahead of need.  `hint`: what the caller knows it will ask
+// for in all (a new segment is made that large if the device has the room).
+static double *arena_alloc(c2r_ctx *c, int set, size_t n, size_t hint = 0) {
   for (;;) {
     if (c->seg_cur[set] < c->segs[set].size()) {
       c2r_ctx::Segment &sg = c->segs[set][c->seg_cur[set]];
@@ -1090,9 +1091,15 @@ static double *arena_alloc(c2r_ctx *c, int set, size_t n) {
     for (const c2r_ctx::Segment &sg : c->segs[set]) have += sg.n;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return nullptr;
-    const size_t room = (size_t)(0.9 * (double)free_b) / sizeof(double);
+    // a set may hold 45 % of what the device could give to column blocks: the two sets alternate, and a set that
+    // took everything would leave the other with batches of a few sources
+    size_t budget = (size_t)(0.45 * ((double)(free_b / sizeof(double)) + (double)c->arena_total));
+    // C2R_ARENA_BUDGET_MB: a smaller budget per set, so that tests reach the release / shrink paths on small meshes
+    if (const char *e = getenv("C2R_ARENA_BUDGET_MB")) budget = std::min(budget, (size_t)(atof(e) * 1.0e6 / sizeof(double)));
+    if (have >= budget) return nullptr;
+    const size_t room = std::min((size_t)(0.9 * (double)free_b) / sizeof(double), budget - have);
     if (n > room) return nullptr;
-    const size_t want = std::min(room, std::max(n, std::max(have / 2, (size_t)1 << 28)));
+    const size_t want = std::min(room, std::max(std::max(n, hint), std::max(have / 2, (size_t)1 << 28)));
     c2r_ctx::Segment sg;
     const auto t0 = std::chrono::steady_clock::now();
     if (hipMalloc(&sg.p, sizeof(double) * want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -1106,6 +1113,20 @@ static double *arena_alloc(c2r_ctx *c, int set, size_t n) {
     c->segs[set].push_back(sg);
     c->arena_total += want;
   }
+}
+
+// Give a set's segments back to the device.  Only when nothing in flight uses them: the caller has waited for the
+// set's last rates launch and has not yet started a sweep on it.
+static void arena_release(c2r_ctx *c, int set) {
+  (void)hipStreamSynchronize(c->stream); // segments are zeroed on the sweep stream
+  for (c2r_ctx::Segment &sg : c->segs[set]) {
+    (void)hipFree(sg.p);
+    c->arena_total -= sg.n;
+    if (c->last_cols >= sg.p && c->last_cols < sg.p + sg.n) c->last_cols = nullptr;
+  }
+  c->segs[set].clear();
+  c->seg_cur[set] = c->seg_used[set] = 0;
+  if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d released, %.2f GB left in all\n", set, c->arena_total * 8e-9);
 }
 
 template <class T>
@@ -1931,24 +1952,40 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   restart_batch:
     run.assign((size_t)nb, SrcRun());
     {
-      // blocks of this batch; when the device has no room for them the batch shrinks
-      for (;;) {
+      // Blocks of this batch.  Segments are kept from batch to batch and pass to pass (allocation is slow), so what
+      // the set holds may be cut for other block sizes than this batch needs (many small segments of a pass with
+      // small boxes).  When the blocks do not fit although less than half of what the set holds is in use, its
+      // segments are given back and made anew in one piece; otherwise the batch is what did fit.
+      for (bool released = false;;) {
         c->seg_cur[set] = 0;
         c->seg_used[set] = 0;
         SrcDev *hs = c->h_src[set];
-        bool fits = true;
-        for (int b = 0; b < nb && fits; b++) {
-          SrcRun &r = run[b];
-          r.ns = mine[b0 + b];
+        size_t total = 0;
+        for (int b = 0; b < nb; b++) total += block_doubles(predicted_cap(mine[b0 + b]));
+        int placed = 0;
+        size_t placed_doubles = 0;
+        for (; placed < nb; placed++) {
+          SrcRun &r = run[placed];
+          r.ns = mine[b0 + placed];
           r.cap = predicted_cap(r.ns);
           const size_t w = (size_t)(2 * r.cap + 1);
-          hs[b].cz = w * w * w;
-          hs[b].cols = arena_alloc(c, set, 6 * hs[b].cz);
-          fits = hs[b].cols != nullptr;
+          hs[placed].cz = w * w * w;
+          hs[placed].cols = arena_alloc(c, set, 6 * hs[placed].cz, total);
+          if (!hs[placed].cols) break;
+          total -= 6 * hs[placed].cz;
+          placed_doubles += 6 * hs[placed].cz;
         }
-        if (fits) break;
-        if (nb == 1) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
-        nb = (nb + 1) / 2;
+        if (placed == nb) break;
+        size_t have = 0;
+        for (const c2r_ctx::Segment &sg : c->segs[set]) have += sg.n;
+        if (!released && have > 0 && placed_doubles < have / 2) {
+          released = true;
+          arena_release(c, set);
+          continue;
+        }
+        if (placed == 0) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
+        if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d: batch of %d cut to the %d sources that fit\n", set, nb, placed);
+        nb = placed; // the same calls place the same blocks again
         run.resize((size_t)nb);
       }
       SrcDev *hs = c->h_src[set];
@@ -2074,6 +2111,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
             pn = std::max(pn, run[b].active ? run[b].nbox + 2 : run[b].nbox);
           }
           if (nb == 1) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
+          if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d: no room to grow in round %d, batch of %d starts over\n", set, round, nb);
           nb = (nb + 1) / 2;
           goto restart_batch;
         }

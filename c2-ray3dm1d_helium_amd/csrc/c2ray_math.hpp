@@ -177,11 +177,13 @@ C2R_MHD double log_table_path(const Log10Arg &a, const double *tab) {
   const double Ln2hi = H[0], Ln2lo = H[1];
   const double *A = H + 2;
   const uint32_t th = a.hx - 0x3FE60000u;
-  const int i2 = (int)((th >> 13) & 127u);
+  // entry i = (th >> 13) & 127 of 16-byte (invc, logc) pairs: its byte offset in two operations
+  const uint32_t off = (th >> 9) & 0x7F0u;
   const int k2 = (int)th >> 20;
   const uint32_t izh = a.hx - (th & 0xFFF00000u);
   const double z = asdouble(((uint64_t)izh << 32) | a.lo);
-  const double invc = tab[2 * i2], logc = tab[2 * i2 + 1];
+  const double *e = (const double *)((const char *)tab + off);
+  const double invc = e[0], logc = e[1];
   const double kd = (double)k2;
   const double r = fma_(z, invc, -1.0);
   const double w = fma_(kd, Ln2hi, logc);

@@ -589,6 +589,56 @@ def test_many_faint_sources_batch_invariance_256(pkg, tables):
     assert 128 * 3 < a[0][3] < 128 * 13 and a[0][4] > 0          # boxes really stopped early
 
 
+def test_column_scratch_release_and_shrinking_batches(pkg, tables, monkeypatch):
+    """The column scratch under pressure (what 512^3 x 1250 sources does to 288 GB, here with C2R_ARENA_BUDGET_MB on
+    a 128^3 mesh): a first pass in neutral gas takes blocks of 4 rounds (12 x 25 MB); in the second the same
+    sources reach the whole mesh (6 x 129^3 doubles = 103 MB each), blocks outgrow the set's budget mid-sweep, the
+    batch starts over with what it has learnt, and batches are cut to the three sources that fit.  Bits must equal
+    an engine that had all the room."""
+    n = 128
+    hp = pkg.hostphys
+    zred = 9.0
+    dr, vol = hp.test_grid(n, zred)
+    nc = n ** 3
+    rng = np.random.default_rng(77)
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc))
+    eps = 1.0e-20
+    xh_n = np.concatenate([np.full(nc, 1.0 - eps), np.full(nc, eps)])
+    xhe_n = np.concatenate([np.full(nc, 1.0 - 2 * eps), np.full(nc, eps), np.full(nc, eps)])
+    x0 = np.full(nc, 1.0e-4)
+    xh_i = np.concatenate([x0, 1.0 - x0])
+    xhe_i = np.concatenate([x0, 1.0 - x0 - 0.1, np.full(nc, 0.1)])
+    srcpos = rng.integers(1, n + 1, size=(12, 3)).astype(np.int32)
+    src = pkg.SourceProps(srcpos, 10.0 ** rng.uniform(4.0, 6.0, 12), 1.0e48)
+    grid = pkg.GridProps((n, n, n), dr, vol)
+    cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+
+    def run():
+        e = pkg.HipEngine((n, n, n), 0)
+        e.set_tables(tables)
+        e.set_sources(src)
+        e.set_batch(12)
+        out = []
+        for xh, xhe in ((xh_n, xhe_n), (xh_i, xhe_i), (xh_n, xhe_n)):
+            mat = pkg.Material(ndens, xh, xhe, None, True, 1.0e4, 1.0, hp.reccoef(1.0e4))
+            e.set_step(mat, grid, cosmo)
+            e.upload_state(mat)
+            e.begin_step()
+            e.set_rates_to_zero()
+            e.pass_sources(1, 1)
+            r = e.download_rates()
+            out.append((r["phih_grid"], r["phihe_grid"], r["photon_loss"][0], r["sum_nbox"]))
+        e.close()
+        return out
+
+    ref = run()
+    assert ref[0][3] < ref[1][3] and ref[1][3] >= 12 * 6   # small boxes first, then (nearly) every source to the mesh limit (7 rounds)
+    monkeypatch.setenv("C2R_ARENA_BUDGET_MB", "350")    # three full-mesh blocks per set
+    tight = run()
+    for a, b in zip(ref, tight):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+
+
 def test_512_cube_heating_three_seds_properties(pkg, gold):
     """BASELINE configs[4]'s mesh with its physics: 512^3, heating on, black-body + power-law + quasar SEDs from
     tables integrated on the device, three box-filling sources.  No oracle at this size: batch 1 against batch 3
