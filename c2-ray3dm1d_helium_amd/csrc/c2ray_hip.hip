@@ -462,6 +462,14 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   __shared__ double s_logtab[256];
   s_logtab[threadIdx.x] = gm::log_table()[threadIdx.x];
   __syncthreads();
+  // two polynomial constants of the log held in vector registers for the whole kernel (gm::LogPins): -0.25 ms per
+  // launch in the isothermal kernel; the heating kernels, which have no registers to spare, lose 2.7 ms with them
+  gm::LogPins pins_ = {0.0, 0.0};
+  const gm::LogPins *pins = nullptr;
+  if (!HEAT) {
+    pins_ = gm::pin_log_constants();
+    pins = &pins_;
+  }
   const int ti = (g.n1 + 7) >> 3, tj = (g.n2 + 7) >> 3;
   // Workgroups are dealt to the 8 XCDs round-robin, and each XCD has its own L2.  A cube reads its columns as 32-byte
   // rows of shell faces, so the other half of every cache line belongs to the neighbouring cube: give each XCD a
@@ -536,10 +544,10 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
       PhotoOut o;
       if (MULTI) {
         const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab);
+        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab, pins);
       } else {
         photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
-                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab);
+                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab, pins);
       }
       a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
       a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);

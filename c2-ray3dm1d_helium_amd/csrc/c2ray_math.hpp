@@ -171,11 +171,33 @@ C2R_MHD Log10Arg log10_split(double x) { // x positive, normal, finite
 }
 C2R_MHD bool log10_near1(const Log10Arg &a) { return a.hx - 0x3FEE0000u < 0x00030900u; }
 C2R_MHD double log10_arg_value(const Log10Arg &a) { return asdouble(((uint64_t)a.hx << 32) | a.lo); }
+// The two polynomial coefficients of the table path that enter as the ADDEND of a three-address fma (fma_kc) must be
+// in vector registers; left to itself the compiler builds them anew in every band iteration (two s_mov and a
+// v_mov_b64 each).  A kernel that evaluates many logs makes them once (pin_log_constants: opaque to the
+// optimiser, so they stay where they are) and hands them down.
+struct LogPins {
+  double a1, a3;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ LogPins pin_log_constants() {
+  const double *A = GMT(log_hdr) + 2;
+  LogPins p;
+  asm volatile("v_mov_b64 %0, %1" : "=v"(p.a1) : "s"(A[1]));
+  asm volatile("v_mov_b64 %0, %1" : "=v"(p.a3) : "s"(A[3]));
+  return p;
+}
+#else
+inline LogPins pin_log_constants() {
+  const double *A = GMT(log_hdr) + 2;
+  return LogPins{A[1], A[3]};
+}
+#endif
 // the table path of __log_fma on x'; `tab` = log_tab (invc, logc pairs), wherever the caller keeps it
-C2R_MHD double log_table_path(const Log10Arg &a, const double *tab) {
+C2R_MHD double log_table_path(const Log10Arg &a, const double *tab, const LogPins *pins = nullptr) {
   const double *H = GMT(log_hdr);
   const double Ln2hi = H[0], Ln2lo = H[1];
   const double *A = H + 2;
+  const double A1 = pins ? pins->a1 : A[1], A3 = pins ? pins->a3 : A[3];
   const uint32_t th = a.hx - 0x3FE60000u;
   // entry i = (th >> 13) & 127 of 16-byte (invc, logc) pairs: its byte offset in two operations
   const uint32_t off = (th >> 9) & 0x7F0u;
@@ -187,13 +209,13 @@ C2R_MHD double log_table_path(const Log10Arg &a, const double *tab) {
   const double kd = (double)k2;
   const double r = fma_(z, invc, -1.0);
   const double w = fma_(kd, Ln2hi, logc);
-  const double t1 = fma_kc(r, A[2], A[1]);
+  const double t1 = fma_kc(r, A[2], A1);
   const double hi_ = r + w;
   const double r2 = r * r;
   double lo_ = (w - hi_) + r;
   lo_ = fma_(kd, Ln2lo, lo_);
   const double r3 = r * r2;
-  const double t2 = fma_kc(r, A[4], A[3]);
+  const double t2 = fma_kc(r, A[4], A3);
   const double s_ = fma_(r2, A[0], lo_);
   const double p_ = fma_(t2, r2, t1);
   const double q_ = fma_(r3, p_, s_);
