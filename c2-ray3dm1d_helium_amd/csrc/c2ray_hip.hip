@@ -425,11 +425,12 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
 // (evolve_point.F90:246-306 with photoion_rates, radiation_photoionrates.f90:108-277).
 // rates layout: [phih | phihe0 | phihe1 | phiheat] each ncell.
 #ifndef C2R_RATES_WAVES_ISO
-#define C2R_RATES_WAVES_ISO 5
+#define C2R_RATES_WAVES_ISO 4
 #endif
 // Waves per SIMD the register allocation aims at.  The kernel is bound by instruction issue at any of these
-// occupancies, so the setting only steers how many copies and spills the allocator makes; measured per variant
-// (heating, one SED: 33.2 / 32.6 / 32.7 ms at 4 / 3 / 2 waves; heating, three SEDs: 443 / 466 / 425 ms).
+// occupancies, so the setting only steers how many copies, spills and waits the compiler makes; measured per variant
+// (isothermal: 20.1 / 19.8 / 19.8 ms at 5 / 4 / 3 waves -- 91 registers either way, so five waves still run;
+// heating, one SED: 31.5 / 29.4 / 29.5 ms at 4 / 3 / 2 waves; heating, three SEDs: 443 / 466 / 425 ms).
 #ifndef C2R_RATES_WAVES_HEAT
 #define C2R_RATES_WAVES_HEAT 3
 #endif
