@@ -314,7 +314,10 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
 // shell_offset(s)+t, so all six stores and -- because the corners of consecutive cells are consecutive
 // cells of the previous shell on every face, the i-faces included -- the twelve corner loads are
 // coalesced.  (In mesh order the i-faces of a shell are one cell per 128-byte line.)
-__global__ void __launch_bounds__(BLOCK)
+#ifndef C2R_SWEEP_WAVES
+#define C2R_SWEEP_WAVES 1
+#endif
+__global__ void __launch_bounds__(BLOCK, C2R_SWEEP_WAVES)
 k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ active, int shell, Box box, StepScalars sc,
               const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
               const double *__restrict__ stateT, const float *__restrict__ lls_grid) {
