@@ -187,6 +187,8 @@ def main():
                     help="config3 from the reference's neutral test-problem start (small sub-boxes, chemistry in its expensive state)")
     a = ap.parse_args()
 
+    # dmabuf IPC for RCCL's peer-to-peer transport on this driver (must be set before the HIP runtime starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # stdout carries ONE line, the result: whatever libraries print there while they start up (gloo, RCCL's version
     # banner) goes to stderr instead
     sys.stdout.flush()
