@@ -29,13 +29,29 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
 
-def config4_inputs(pkg, n=256, nsrc=1024, seed=2024, heating=False):
+def correlated_unit_field(white, n, index):
+    """The white Gaussian field `white` (n^3, unit variance) filtered to a power spectrum P(k) ~ k^-index and
+    scaled back to unit variance: densities that vary smoothly from cell to cell, like an N-body snapshot."""
+    f = np.fft.rfftn(white.reshape(n, n, n))
+    k1 = np.fft.fftfreq(n) * n
+    kz = np.fft.rfftfreq(n) * n
+    k2 = k1[:, None, None] ** 2 + k1[None, :, None] ** 2 + kz[None, None, :] ** 2
+    k2[0, 0, 0] = 1.0
+    f *= k2 ** (-0.25 * index)
+    f[0, 0, 0] = 0.0
+    out = np.fft.irfftn(f, s=(n, n, n)).reshape(-1)
+    return out / out.std()
+
+
+def config4_inputs(pkg, n=256, nsrc=1024, seed=2024, heating=False, corr_index=0.0):
     hp = pkg.hostphys
     zred = 9.0
     dr, vol = hp.test_grid(n, zred)
     nc = n ** 3
     rng = np.random.default_rng(seed)
     ln = rng.normal(0.0, 1.0, nc)
+    if corr_index > 0.0:
+        ln = correlated_unit_field(ln, n, corr_index)
     ndens = hp.test_density(zred) * np.exp(ln - 0.5)          # mean-preserving log-normal
     srcpos = rng.integers(1, n + 1, size=(nsrc, 3)).astype(np.int32)
     flux = 10.0 ** rng.uniform(52.0, 54.0, nsrc) / 1.0e48
@@ -78,6 +94,8 @@ def main():
     ap.add_argument("--heating", action="store_true")
     ap.add_argument("--config5", action="store_true")
     ap.add_argument("--pl", action="store_true", help="the SEDs, heating and device-built tables of --config5 at --mesh / --sources")
+    ap.add_argument("--correlated", type=float, default=0.0, metavar="INDEX",
+                    help="log-density with power spectrum k^-INDEX (e.g. 2.5) instead of white noise: neighbouring cells alike")
     ap.add_argument("--headline", action="store_true", help="bench.py's workload instead (256^3, 8 bright sources, pre-ionised gas): for --lane-census")
     ap.add_argument("--lane-census", action="store_true",
                     help="library built with -DC2R_RATES_COUNT: per iteration, how well k_rates' band loop fills its lanes")
@@ -93,7 +111,7 @@ def main():
         a.sources, a.ranks, a.rank = 8, 1, 0
         mat, grid, src, cosmo = bench.config3_inputs(pkg, n, 8, heating=a.heating)
     else:
-        mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating)
+        mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating, corr_index=a.correlated)
     tables = pkg.RadiationTables.load()
     if a.config5:
         gold = ROOT / "tests" / "golden"
