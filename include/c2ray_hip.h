@@ -127,7 +127,8 @@ int c2r_evolve3d(c2r_ctx *ctx, double dt, int *niter_out, int *conv_flags_out, i
 /* The pieces of evolve3D, for hosts that drive the loop themselves (multi-rank runs reduce the
  * rate grids between c2r_pass_sources and c2r_global_pass):
  *   c2r_begin_step      evolve.F90:131-136  xh_av = xh_intermed = xh, xhe_* likewise
- *   c2r_set_rates_to_zero evolve.F90:371-381
+ *   c2r_set_rates_to_zero evolve.F90:371-381 (carried out by the next pass's first rates launch, or by whoever reads
+ *                       the grids first: nothing observable differs)
  *   c2r_pass_sources    do_grid_static (master_slave.F90:74-96): do_source for ns = first,
  *                       first+stride, ... <= NumSrc (1-based) -- evolve_source.F90:66-238
  *   c2r_global_pass     evolve.F90:435-501 loop: evolve0D_global for every cell
