@@ -7,6 +7,7 @@ and every output file they write must be byte-identical.
 The binaries are built in the dev container (they contain compiled reference code, so they are
 git-ignored) and travel to the GPU box with the snapshot; without them the test is skipped."""
 import filecmp
+import json
 import sys
 from pathlib import Path
 
@@ -16,6 +17,21 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, str(ROOT / "oracle"))
+
+
+def _reference_snapshot(golden_name, run_reference):
+    """What the all-reference binary produced for a case: from the fixture tests/golden/<golden_name> (made by
+    oracle/make_golden_dropin.py from a run of that binary in the dev container -- the two cases whose reference
+    run spends a minute or more integrating the PL / QPL tables on the host), or, with C2R_DROPIN_RUN_REFERENCE=1
+    or without a fixture, from running it now (`run_reference()` returns the run directory)."""
+    import json
+    import os
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import make_golden_dropin
+    path = ROOT / "tests" / "golden" / golden_name if golden_name else None
+    if path is not None and path.exists() and not os.environ.get("C2R_DROPIN_RUN_REFERENCE"):
+        return json.loads(path.read_text())
+    return json.loads(json.dumps(make_golden_dropin.snapshot(run_reference())))   # same types as the fixture
 
 
 @pytest.mark.parametrize("iso,pl,sources", [
@@ -59,14 +75,21 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
     tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "")
-    r1 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test", name=f"dropin_ref_{tag}", pl=pl, lls=lls)
+    import make_golden_dropin
+    if pl:
+        assert sources == make_golden_dropin.PL_SOURCES and not iso     # what the fixture was made from
+    s1 = _reference_snapshot("dropin_ref_heat_pl.json" if pl else None,
+                             lambda: refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test",
+                                                          name=f"dropin_ref_{tag}", pl=pl, lls=lls))
     r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls)
-    files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
-    assert len(files) >= 15, files
-    for f in files:
-        assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), f
+    s2 = json.loads(json.dumps(make_golden_dropin.snapshot(r2)))
+    assert len(s1["sha256"]) >= 15, sorted(s1["sha256"])
+    # every output file byte for byte (SHA-256 of the reference's file against the drop-in's)
+    assert sorted(s1["sha256"]) == sorted(s2["sha256"])
+    for f in s1["sha256"]:
+        assert s1["sha256"][f] == s2["sha256"][f], f
     # same iteration history in the log
-    assert refrun.parse_log(r1) == refrun.parse_log(r2)
+    assert s1["log_calls"] == s2["log_calls"]
     log2 = (r2 / "results" / "C2Ray.log").read_text(errors="replace")
     if devtables:
         assert "tables built on the device for SED  0" in log2
@@ -75,21 +98,17 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     if ngpu2:
         assert "devices per rank:   2" in log2
     # the reference's "min xh_av" / "min xhe_av" lines (evolve.F90:463-466), from a device minimum: same numbers
-    import re
-    mins = lambda run: re.findall(r"min xhe?_av:\s+(\S+)", (run / "results" / "C2Ray.log").read_text(errors="replace"))
-    assert len(mins(r1)) > 0 and mins(r1) == mins(r2)
+    assert len(s1["mins"]) > 0 and s1["mins"] == s2["mins"]
     # photon statistics (written from host arrays the HIP path filled): compare the numbers
-    a = (r1 / "results" / "PhotonCounts2.out").read_text().split()
-    b = (r2 / "results" / "PhotonCounts2.out").read_text().split()
-    assert a == b
+    assert s1["photoncounts2"] == s2["photoncounts2"]
     # PhotonCounts.out (unit 90, report_photonstatistics): one line per global pass plus one per
     # evolve3D call, in both runs; the HIP shim fills it from grid sums reduced on the device (a
     # different summation order: equal to the printed 4 digits, up to a last-digit flip)
     import numpy as np
 
-    def numbers(path):
+    def numbers(text):
         rows = []
-        for line in path.read_text().splitlines():
+        for line in text.splitlines():
             try:
                 v = [float(x) for x in line.split()]
             except ValueError:
@@ -98,9 +117,9 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
                 rows.append(v)
         return np.array(rows)
 
-    pa = numbers(r1 / "results" / "PhotonCounts.out")
-    pb = numbers(r2 / "results" / "PhotonCounts.out")
-    calls = refrun.parse_log(r1)
+    pa = numbers(s1["photoncounts"])
+    pb = numbers(s2["photoncounts"])
+    calls = s1["log_calls"]
     assert pa.shape == pb.shape and pa.shape[0] == sum(len(c) + 1 for c in calls)
     # columns: total_ion, totalsrc, recomions, photon_loss, totrec, totcollisions, 3 ratios.  total_ion
     # is a difference of two large sums (before - after), so compare it relative to the source term
@@ -153,16 +172,17 @@ def test_cubep3m_material_through_the_dropin():
     hip = refrun.REFDIR / "N16_cubep3m" / "C2Ray_3D_hip"
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref/N16_cubep3m binaries not present (built only where /root/reference exists)")
-    sources = [(8, 8, 8, 3e59, 1e59, 0.0), (2, 15, 4, 0.0, 5e58, 2e59), (16, 1, 9, 2e59, 0.0, 5e58)]
-    r1 = refrun.run_cubep3m(16, sources, which="test", name="dropin_cubep3m_ref")
+    import json
+    import make_golden_dropin
+    sources = make_golden_dropin.CUBEP3M_SOURCES
+    s1 = _reference_snapshot("dropin_ref_cubep3m.json", lambda: refrun.run_cubep3m(16, sources, which="test", name="dropin_cubep3m_ref"))
     r2 = refrun.run_cubep3m(16, sources, which="hip", name="dropin_cubep3m_hip")
-    files = sorted(p.name for p in (r1 / "results").glob("*.bin"))
-    assert len(files) >= 10, files
-    for f in files:
-        assert filecmp.cmp(r1 / "results" / f, r2 / "results" / f, shallow=False), f
-    a, b = refrun.parse_log(r1), refrun.parse_log(r2)
+    s2 = json.loads(json.dumps(make_golden_dropin.snapshot(r2)))
+    assert len(s1["sha256"]) >= 10, sorted(s1["sha256"])
+    assert sorted(s1["sha256"]) == sorted(s2["sha256"])
+    for f in s1["sha256"]:
+        assert s1["sha256"][f] == s2["sha256"][f], f
+    a, b = s1["log_calls"], s2["log_calls"]
     assert a == b and len(a) == 2 and len(a[0]) > 100
-    log1 = (r1 / "results" / "C2Ray.log").read_text(errors="replace")
-    assert "clumping input from ../coarser_densities/halos_included/9.000n_all.dat" in log1
-    assert "density input from ../coarser_densities/halos_removed/9.000n_all.dat" in log1
-    assert "(type  5 )" in log1 and "(type  2 )" in log1
+    # both runs read the generated snapshot through the reference's own ingest
+    assert len(s1["log_markers"]) == 4 and s1["log_markers"] == s2["log_markers"]
