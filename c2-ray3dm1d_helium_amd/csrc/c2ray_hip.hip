@@ -147,6 +147,21 @@ __device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
   return sqrt(1.0 + (dj * dj + dk * dk) / (di * di));
 }
 
+// Where the six columns of the cell at shell position p live in a source's block of 6 cz doubles: the three incoming
+// columns of a cell side by side (24 bytes), then all outgoing ones likewise.  The rates kernel, whose 4 x 4 x 4 cubes
+// read rows of four cells, then uses 96 of every 128 bytes it touches instead of 32 (-0.3..0.5 ms per launch at
+// 256^3 x 8); the sweep's stores become three strided ones per triple (+0.05..0.1 ms per pass).
+#ifndef C2R_COLS_AOS
+#define C2R_COLS_AOS 1
+#endif
+// 0: six arrays; 1: both triples side by side; 2: only the incoming ones; 3: only the outgoing ones
+__host__ __device__ inline size_t col_in(size_t p, int k, size_t cz) {
+  return (C2R_COLS_AOS == 1 || C2R_COLS_AOS == 2) ? 3 * p + (size_t)k : p + (size_t)k * cz;
+}
+__host__ __device__ inline size_t col_out(size_t p, int k, size_t cz) {
+  return (C2R_COLS_AOS == 1 || C2R_COLS_AOS == 3) ? 3 * cz + 3 * p + (size_t)k : p + (size_t)(3 + k) * cz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (i,j,k) -> (j,i,k) copies of the four state grids the sweep reads, so that the cells of a
 // shell's i-faces (fixed i, consecutive j) are consecutive in memory too.  32x32 tiles through LDS.
@@ -213,8 +228,8 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
       const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
       const double *cs = S.cols;
-      const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
-      const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
+      const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
+      const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
       if (cin_HI < max_coldensh) {
         double vol_ph;
         if (shell == 0) {
@@ -279,8 +294,8 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
       const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
       const double *cs = S.cols;
-      const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
-      const double cout_HI = cs[p + 3 * cz], cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
+      const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
+      const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
       if (cin_HI < max_coldensh) {
         double vol_ph;
         if (shell == 0) {
@@ -309,11 +324,11 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
 // ---------------------------------------------------------------------------------------------
 // Column sweep of one shell for every active source of the batch (blockIdx.y counts `active`).
 // evolve0D, files_for_3D/evolve_point.F90:114-168 and :237-244, with cinterp (column_density.f90:28-345).
-// A source's column block in the arena: [6][cz] = N_in(HI,HeI,HeII), N_out(HI,HeI,HeII), each array in SHELL
-// ORDER (shell_position of the cell's offset from its source): thread t of shell s owns entry
-// shell_offset(s)+t, so all six stores and -- because the corners of consecutive cells are consecutive
-// cells of the previous shell on every face, the i-faces included -- the twelve corner loads are
-// coalesced.  (In mesh order the i-faces of a shell are one cell per 128-byte line.)
+// A source's column block in the arena: 6 cz doubles = N_in(HI,HeI,HeII) of every cell, then N_out(HI,HeI,HeII)
+// (col_in / col_out), the cells in SHELL ORDER (shell_position of the cell's offset from its source): thread t of
+// shell s owns entry shell_offset(s)+t, so the stores of a wave cover one contiguous range and -- because the
+// corners of consecutive cells are consecutive cells of the previous shell on every face, the i-faces included --
+// so do the corner loads.  (In mesh order the i-faces of a shell are one cell per 128-byte line.)
 #ifndef C2R_SWEEP_WAVES
 #define C2R_SWEEP_WAVES 1
 #endif
@@ -373,10 +388,12 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
     size_t qc[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) qc[c] = shell_position(s4.ci[c], s4.cj[c], s4.ck[c]);
-    const double *oH = cs + 3 * cz, *oHe0 = cs + 4 * cz, *oHe1 = cs + 5 * cz;
-    cin_HI = interp_column(s4, oH[qc[0]], oH[qc[1]], oH[qc[2]], oH[qc[3]], sigma_HI_at_ion_freq);
-    cin_HeI = interp_column(s4, oHe0[qc[0]], oHe0[qc[1]], oHe0[qc[2]], oHe0[qc[3]], sigma_HeI_at_ion_freq);
-    cin_HeII = interp_column(s4, oHe1[qc[0]], oHe1[qc[1]], oHe1[qc[2]], oHe1[qc[3]], sigma_HeII_at_ion_freq);
+    cin_HI = interp_column(s4, cs[col_out(qc[0], 0, cz)], cs[col_out(qc[1], 0, cz)], cs[col_out(qc[2], 0, cz)],
+                           cs[col_out(qc[3], 0, cz)], sigma_HI_at_ion_freq);
+    cin_HeI = interp_column(s4, cs[col_out(qc[0], 1, cz)], cs[col_out(qc[1], 1, cz)], cs[col_out(qc[2], 1, cz)],
+                            cs[col_out(qc[3], 1, cz)], sigma_HeI_at_ion_freq);
+    cin_HeII = interp_column(s4, cs[col_out(qc[0], 2, cz)], cs[col_out(qc[1], 2, cz)], cs[col_out(qc[2], 2, cz)],
+                             cs[col_out(qc[3], 2, cz)], sigma_HeII_at_ion_freq);
     path = s4.path * sc.dr1;
     if (sc.use_lls) {
       // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180); the per-cell
@@ -389,12 +406,12 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
   const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
   const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
   const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
-  cs[p] = cin_HI;
-  cs[p + cz] = cin_HeI;
-  cs[p + 2 * cz] = cin_HeII;
-  cs[p + 3 * cz] = cout_HI;
-  cs[p + 4 * cz] = cout_HeI;
-  cs[p + 5 * cz] = cout_HeII;
+  cs[col_in(p, 0, cz)] = cin_HI;
+  cs[col_in(p, 1, cz)] = cin_HeI;
+  cs[col_in(p, 2, cz)] = cin_HeII;
+  cs[col_out(p, 0, cz)] = cout_HI;
+  cs[col_out(p, 1, cz)] = cout_HeI;
+  cs[col_out(p, 2, cz)] = cout_HeII;
 }
 
 // photon_loss_src_thread(tn) += ... (evolve_point.F90:312): sum the block partials of all shells of
@@ -420,7 +437,7 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
             dk = wrap0(k + 1 - S.k0 + g.l3, g.n3) - g.l3;
   const bool inside = di >= S.lo[0] && di <= S.hi[0] && dj >= S.lo[1] && dj <= S.hi[1] && dk >= S.lo[2] && dk <= S.hi[2];
   const size_t p = shell_position(di, dj, dk);
-  for (int c = 0; c < 3; c++) out[q + c * g.ncell] = inside ? cs[p + (size_t)(3 + c) * S.cz] : 0.0;
+  for (int c = 0; c < 3; c++) out[q + c * g.ncell] = inside ? cs[col_out(p, c, S.cz)] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -532,9 +549,9 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     const size_t cz = S.cz;
     const size_t p = shell_position(di, dj, dk);
     const double *cs = S.cols;
-    const double cout_HI = cs[p + 3 * cz];
-    const double cin_HI = cs[p], cin_HeI = cs[p + cz], cin_HeII = cs[p + 2 * cz];
-    const double cout_HeI = cs[p + 4 * cz], cout_HeII = cs[p + 5 * cz];
+    const double cout_HI = cs[col_out(p, 0, cz)];
+    const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
+    const double cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
     double vol_ph;
     if (di == 0 && dj == 0 && dk == 0) {
       vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
@@ -2132,9 +2149,15 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         SrcDev &S = c->h_src[set][act[a]];
         const size_t wn = (size_t)(2 * ncap + 1), ncz = wn * wn * wn;
         const size_t wp = (size_t)(2 * r.smax_prev + 1), have = r.smax_prev >= 0 ? wp * wp * wp : 0;
-        for (int k = 0; k < 6 && have > 0; k++)
-          HIPCHK(c, hipMemcpyAsync(ncols + (size_t)k * ncz, S.cols + (size_t)k * S.cz, sizeof(double) * have,
-                                   hipMemcpyDeviceToDevice, c->stream));
+        // the shells stored so far are a prefix of each array (or of each array of triples)
+        for (int half = 0; half < 2 && have > 0; half++) {
+          const bool triples = C2R_COLS_AOS == 1 || C2R_COLS_AOS == (half ? 3 : 2);
+          for (int k = 0; k < (triples ? 1 : 3); k++) {
+            const size_t at = (size_t)(3 * half + k);
+            HIPCHK(c, hipMemcpyAsync(ncols + at * ncz, S.cols + at * S.cz, sizeof(double) * (triples ? 3 : 1) * have,
+                                     hipMemcpyDeviceToDevice, c->stream));
+          }
+        }
         S.cols = ncols;
         S.cz = ncz;
         r.cap = ncap;
