@@ -147,6 +147,14 @@ __device__ __forceinline__ double sc_path(int idel, int jdel, int kdel) {
   return sqrt(1.0 + (dj * dj + dk * dk) / (di * di));
 }
 
+// A pointer that comes out of a record in memory (SrcDev::cols) is a generic pointer to the compiler, which then uses
+// flat loads and stores; the column blocks are device memory.
+#ifdef C2R_FLAT_COLS
+typedef double global_double;
+#else
+typedef __attribute__((address_space(1))) double global_double;
+#endif
+
 // Where the six columns of the cell at shell position p live in a source's block of 6 cz doubles: the three incoming
 // columns of a cell side by side (24 bytes), then all outgoing ones likewise.  The rates kernel, whose 4 x 4 x 4 cubes
 // read rows of four cells, then uses 96 of every 128 bytes it touches instead of 32 (-0.3..0.5 ms per launch at
@@ -227,7 +235,7 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
     if (inside && boundary) {
       const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      const double *cs = S.cols;
+      const global_double *cs = (const global_double *)S.cols;
       const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
       const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
       if (cin_HI < max_coldensh) {
@@ -293,7 +301,7 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
     if (inside && boundary) {
       const size_t cz = S.cz;
       const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      const double *cs = S.cols;
+      const global_double *cs = (const global_double *)S.cols;
       const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
       const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
       if (cin_HI < max_coldensh) {
@@ -359,7 +367,7 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
   if (!inside) return;
   const size_t nc = g.ncell, cz = S.cz;
   const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-  double *cs = S.cols;
+  global_double *cs = (global_double *)S.cols;
   double nd, h0, he0, he1;
   const int w_ = 2 * shell + 1;
   if (stateT && shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
@@ -548,7 +556,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     touched = true;
     const size_t cz = S.cz;
     const size_t p = shell_position(di, dj, dk);
-    const double *cs = S.cols;
+    const global_double *cs = (const global_double *)S.cols;
     const double cout_HI = cs[col_out(p, 0, cz)];
     const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
     const double cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
