@@ -212,10 +212,13 @@ k_transpose_ij(Grid g, Ptr4 P) {
 __global__ void __launch_bounds__(BLOCK)
 k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int multi, int s_lo, int s_hi, Box box,
        StepScalars sc, const BandData *__restrict__ bd, SedSet ss,
-       const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
+       const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample, int first_block) {
+  // first_block: the blocks before it hold no surface cell (the host has set their partials to zero and does not
+  // launch them); block numbers, and with them the order of the sum, stay what they are
   __shared__ double sh[BLOCK / 64];
   const SrcDev &S = src[list[blockIdx.y]];
-  const int B = block_base[s_lo] + (int)blockIdx.x * sample;
+  const int bx = first_block + (int)blockIdx.x;
+  const int B = block_base[s_lo] + bx * sample;
   int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -261,7 +264,7 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
     }
   }
   const double bs = block_sum(loss, sh);
-  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + blockIdx.x] = bs;
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + bx] = bs;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1858,9 +1861,19 @@ static int boundary_loss(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (ensure_pair<double>(c, &c->d_loss_partial, (double **)nullptr, &c->loss_partial_cap, need)) return 1;
   }
-  hipLaunchKernelGGL(k_loss, dim3(nblk, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
+  // a surface cell has one coordinate on a face of the box, so its shell is at least the nearest face's distance:
+  // the shells before that hold none, their blocks are not launched and their partial sums are set to zero
+  int first_block = 0;
+  if (sample == 1) {
+    int s_first = 1 << 30;
+    for (int d = 0; d < 3; d++) s_first = std::min(s_first, std::min(std::abs(box.lo[d]), std::abs(box.hi[d])));
+    s_first = std::min(std::max(s_first, s_lo), s_hi);
+    first_block = c->block_base[s_first] - c->block_base[s_lo];
+    if (first_block > 0) HIPCHK(c, zero_device(c->d_loss_partial, sizeof(double) * need, c->stream));
+  }
+  hipLaunchKernelGGL(k_loss, dim3(nblk - first_block, n), dim3(BLOCK), 0, c->stream, c->g, c->d_src[set], c->d_list[set] + list_off,
                      multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_bands, ss, c->d_block_base, c->d_loss_partial, nblk,
-                     sample);
+                     sample, first_block);
   hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, c->stream, c->d_loss_partial, nblk, nblk, c->d_loss_acc);
   c->tm.sweep_launches += 2;
   HIPCHK(c, hipGetLastError());
