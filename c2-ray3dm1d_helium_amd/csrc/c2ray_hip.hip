@@ -2635,15 +2635,15 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
     // within a millisecond
     c->chem_b1 = c->chem_b1_next;
     if (c->chem_b1 == 0 && ncells >= (size_t)64 * 64 * C2R_CHEM_BLOCK) {
-      int hist[CHEM_HIST];
+      int ctl[2 + CHEM_HIST]; // the two list counts, then the histogram (the layout of d_chemctl)
       c->chem_sample = 512;
       if (launch_chemistry(c, st, dt, first_cell, ncells, nullptr, c->chem_sample, c->d_defer[0], c->d_chemctl, 1)) return 1;
-      HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl, sizeof(int) * (2 + CHEM_HIST), hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(ctl, c->d_chemctl, sizeof ctl, hipMemcpyDeviceToHost, st));
       HIPCHK(c, hipStreamSynchronize(st));
-      const int dropped = hist[0];
+      const int dropped = ctl[0];
       // cells the sample dropped count as "above 512"
       int h2[CHEM_HIST];
-      for (int b = 0; b < CHEM_HIST; b++) h2[b] = hist[2 + b];
+      for (int b = 0; b < CHEM_HIST; b++) h2[b] = ctl[2 + b];
       h2[11] += dropped;
       c->chem_b1 = chemistry_ceiling(h2);
       // the few cells the sample dropped are long chains: they restart at once, without ceiling, beside the bulk

@@ -11,6 +11,16 @@
 // separate roundings everywhere else (the file must be compiled with -ffp-contract=off).
 // Tables: csrc/c2ray_math_tables.hpp (generated, data only).
 //
+// Provenance and licence: this is third-party arithmetic, not the reference's.  The algorithms and coefficient
+// tables are those of glibc 2.35's sysdeps/ieee754/dbl-64/e_exp.c, e_log.c, e_pow.c (from ARM's
+// optimized-routines; Copyright (C) 2018-2022 Free Software Foundation, Inc., originally Copyright (c) 2018 Arm
+// Ltd., MIT) and e_log10.c (fdlibm; Copyright (C) 1993 Sun Microsystems, Inc., "permission to use, copy, modify,
+// and distribute this software is freely granted, provided that this notice is preserved"), distributed with
+// glibc under the GNU Lesser General Public License v2.1 or later.  The restatement below is written from the
+// published algorithm and the disassembly of the image's libm.so.6; the tables in c2ray_math_tables.hpp are
+// data lifted from that binary by tools/extract_glibc_math_tables.py.  A redistributor must honour LGPL-2.1+
+// for this file and its tables.
+//
 // Domain: finite, positive, normal arguments as they occur on the hot path; anything else (zero,
 // negative, subnormal, inf, nan, |y| < 2^-65 or >= 2^63 in pow) is forwarded to the platform libm.
 #pragma once

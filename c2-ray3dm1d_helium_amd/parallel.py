@@ -1,19 +1,14 @@
-"""Sources over ranks, one all-reduce of the rate grids per outer iteration.
+"""Sources over ranks with the sum carried by torch.distributed: the TEST TRANSPORT of the host loop.
 
-The reference's only distributed strategy: every rank holds the full grid,
-rank r sweeps sources r+1, r+1+npr, ... (master_slave.F90:85), then
-mpi_accumulate_grid_quantities (evolve.F90:505-548) sums four grids, photon_loss(47) and sum_nbox
-with six MPI_ALLREDUCE calls.  Here that is ONE fp64 SUM all-reduce over the contiguous buffer
-[phih | phihe(0) | phihe(1) | phiheat | photon_loss(1:47) | sum_nbox] through torch.distributed
-(backend "nccl" == RCCL over xGMI on the GPUs; "gloo" in the CPU tests).
-
-On the GPUs the sum is pipelined with the pass before it and the global pass after it
-(`pass_allreduce_chemistry`): the rates launch of a rank's last batch is cut into slabs of k-planes, the
-all-reduce of slab s (3 or 4 component ranges of the buffer) runs on RCCL's stream while the device computes
-the rates of slabs s+1..., and the chemistry of slab s is queued behind the event that marks its sum complete,
-i.e. it runs while later slabs are still on the wire.  xGMI is point to point -- two ranks share one link,
-~50 GB/s per direction -- so 403 MB per iteration at 256^3 would otherwise cost ~10 ms next to a 34 ms
-iteration.  Cutting costs ~0.2 ms per slab (kernel tails, partly hidden by alternating streams); default 4.
+The product's sum over ranks lives inside the library (csrc/c2ray_comm.inc: c2r_comm_init, c2r_allreduce_rates,
+c2r_pass_allreduce_chemistry -- one RCCL all-reduce of the contiguous buffer, or slab-wise and overlapped with the
+pass and the chemistry); bench.py and the Fortran drop-in use that.  This module keeps the same host loop
+(rank r sweeps sources r+1, r+1+npr, ... as master_slave.F90:85, then one fp64 SUM over
+[phih | phihe(0) | phihe(1) | phiheat | photon_loss(1:47) | sum_nbox] as mpi_accumulate_grid_quantities,
+evolve.F90:505-548, then the replicated global pass) over a torch.distributed process group, so that the
+distribution logic can be exercised where RCCL cannot run: world_size 2 over gloo on the CPU with the oracle as
+engine (tests/test_host_logic.py), and several ranks sharing one GPU over gloo (tests/test_gpu_multirank.py;
+RCCL refuses ranks that share a device).  It is not a second production path.
 """
 from __future__ import annotations
 
