@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/c2ray_hip.h"
@@ -51,6 +52,9 @@ struct SrcDev {
   double nflux_sed[2]; // NormFluxPL(ns), NormFluxQPL(ns) (-DPL / -DQUASARS builds), else 0
   double *cols;        // this source's column block in the scratch arena
   size_t cz;           // entries per column array of that block: (2*cap+1)^3, cap = shells the block can hold
+  int loss_lo;         // >= 0: the rates launch leaves, for every surface cell of the final sub-box in shells >= loss_lo,
+                       // the photons that leave the box through it in the cell's N_in(HI) slot (k_loss_stored adds
+                       // them up); -1: no such request (set before the rates launch)
 };
 // the sub-box of the round in flight: the same for every active source of a batch (all are in the same round)
 struct Box {
@@ -268,6 +272,46 @@ k_loss(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same sum from values the rates kernel has left behind.  The loss that is KEPT for a source whose last round
+// ended for geometric reasons (the box cannot grow any further, evolve_source.F90:136-139) decides nothing, and
+// its terms -- photo_out * vol / vol_ph of the surface cells, evolve_point.F90:310-315 -- are quantities k_rates
+// computes anyway for every cell.source (the reference takes them from the same photoion_rates call, phi%photo_out).
+// So k_rates stores them (SrcDev::loss_lo) in the cell's N_in(HI) slot of the column block, which nobody reads
+// after it, and this kernel adds them up with k_loss's thread <-> cell map, block partials and block order: the
+// same bits as k_loss gives, without evaluating a single band a second time.
+__global__ void __launch_bounds__(BLOCK)
+k_loss_stored(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int s_lo, int s_hi, Box box,
+              const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int first_block) {
+  __shared__ double sh[BLOCK / 64];
+  const SrcDev &S = src[list[blockIdx.y]];
+  const int bx = first_block + (int)blockIdx.x;
+  const int B = block_base[s_lo] + bx;
+  int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_base[mid] <= B) lo = mid; else hi = mid - 1;
+  }
+  const int shell = lo;
+  const long long cnt = shell_count(shell);
+  const long long t = (long long)(B - block_base[shell]) * BLOCK + threadIdx.x;
+  double loss = 0.0;
+  if (t < cnt) {
+    int di, dj, dk;
+    shell_decode(shell, (int)t, di, dj, dk);
+    const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
+                        dk <= box.hi[2];
+    const bool boundary = di == box.lo[0] || dj == box.lo[1] || dk == box.lo[2] || di == box.hi[0] || dj == box.hi[1] ||
+                          dk == box.hi[2];
+    if (inside && boundary) {
+      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
+      loss = ((const global_double *)S.cols)[col_in(p, 0, S.cz)];
+    }
+  }
+  const double bs = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + bx] = bs;
+}
+
+// ---------------------------------------------------------------------------------------------
 // A quick LOWER BOUND of that loss, to decide "this source goes on" without waiting for the full sum: of every
 // `sample`-th block of the round's shells, 8 cells (every 32nd), each cell's bands spread over 32 lanes -- a thread
 // evaluates one or two bands, so the launch lasts microseconds where a thread of k_loss walks all bands of
@@ -438,6 +482,89 @@ k_loss_finish(const double *__restrict__ loss_partial, int pitch, int count, dou
   if (threadIdx.x == 0) loss_acc[blockIdx.x] = tot;
 }
 
+// The probes of several rounds of a batch in ONE launch (blockIdx.z counts the rounds): the rounds that were swept on
+// trust are probed together, and two launches (this one and k_loss_finish_rounds) instead of two per round keep the
+// probe's footprint on the device at a few microseconds.
+struct ProbeRound {
+  int s_lo, s_hi;   // shells of the round
+  Box box;          // its sub-box
+  int list_off;     // its active list in the batch's list buffer
+  int nact;         // sources in that list
+  int nblk;         // sampled blocks per source
+  int partial_off;  // first partial sum of the round (nblk per source)
+  int acc_off;      // first result of the round (one per source)
+};
+__global__ void __launch_bounds__(BLOCK)
+k_loss_probe_rounds(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lists, const ProbeRound *__restrict__ rounds,
+                    int multi, StepScalars sc, const BandData *__restrict__ bd, SedSet ss, const int *__restrict__ block_base,
+                    double *__restrict__ loss_partial, int sample) {
+  __shared__ double sh[BLOCK / 64];
+  const ProbeRound &R = rounds[blockIdx.z];
+  if ((int)blockIdx.x >= R.nblk || (int)blockIdx.y >= R.nact) return; // uniform per block
+  const SrcDev &S = src[lists[R.list_off + blockIdx.y]];
+  const int s_lo = R.s_lo, s_hi = R.s_hi;
+  // every sample-th block counted from the END of the round (see k_loss_probe)
+  const int B = block_base[s_hi + 1] - 1 - (int)blockIdx.x * sample;
+  int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_base[mid] <= B) lo = mid; else hi = mid - 1;
+  }
+  const int shell = lo;
+  const long long cnt = shell_count(shell);
+  const int slot = threadIdx.x & 31;
+  const long long t = (long long)(B - block_base[shell]) * BLOCK + (threadIdx.x >> 5) * 32;
+  double loss = 0.0;
+  if (t < cnt) {
+    int di, dj, dk;
+    shell_decode(shell, (int)t, di, dj, dk);
+    const bool inside = di >= R.box.lo[0] && di <= R.box.hi[0] && dj >= R.box.lo[1] && dj <= R.box.hi[1] && dk >= R.box.lo[2] &&
+                        dk <= R.box.hi[2];
+    const bool boundary = di == R.box.lo[0] || dj == R.box.lo[1] || dk == R.box.lo[2] || di == R.box.hi[0] || dj == R.box.hi[1] ||
+                          dk == R.box.hi[2];
+    if (inside && boundary) {
+      const size_t cz = S.cz;
+      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
+      const global_double *cs = (const global_double *)S.cols;
+      const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
+      const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
+      if (cin_HI < max_coldensh) {
+        double vol_ph;
+        if (shell == 0) {
+          vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
+        } else {
+          const double path = sc_path(di, dj, dk) * sc.dr1;
+          const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
+          vol_ph = 4.0 * pi * (xs * xs + ys * ys + zs * zs) * path;
+        }
+        const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+        double po = 0.0;
+        for (int sd = 0; sd < (multi ? NSED : 1); sd++) {
+          if (!(nf[sd] > 0.0)) continue;
+          for (int b = ss.lo[sd] + slot; b < ss.hi[sd]; b += 32)
+            po += photo_out_band(*bd, sd, ss.photo_thick[sd], ss.photo_thin[sd], b, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII,
+                                 cout_HeII, nf[sd]);
+        }
+        loss = po * sc.vol / vol_ph;
+      }
+    }
+  }
+  const double bs = block_sum(loss, sh);
+  if (threadIdx.x == 0) loss_partial[(size_t)R.partial_off + (size_t)blockIdx.y * R.nblk + blockIdx.x] = bs;
+}
+// the partial sums of (round blockIdx.y, source blockIdx.x) added up, fixed shape as k_loss_finish
+__global__ void __launch_bounds__(BLOCK)
+k_loss_finish_rounds(const ProbeRound *__restrict__ rounds, const double *__restrict__ loss_partial, double *__restrict__ loss_acc) {
+  __shared__ double sh[BLOCK / 64];
+  const ProbeRound &R = rounds[blockIdx.y];
+  if ((int)blockIdx.x >= R.nact) return;
+  const double *p = loss_partial + (size_t)R.partial_off + (size_t)blockIdx.x * R.nblk;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < R.nblk; i += BLOCK) a += p[i];
+  const double tot = block_sum(a, sh);
+  if (threadIdx.x == 0) loss_acc[R.acc_off + blockIdx.x] = tot;
+}
+
 // columns of one slot from shell order back to mesh order (diagnostic download only)
 __global__ void __launch_bounds__(BLOCK)
 k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restrict__ out) {
@@ -559,7 +686,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     touched = true;
     const size_t cz = S.cz;
     const size_t p = shell_position(di, dj, dk);
-    const global_double *cs = (const global_double *)S.cols;
+    global_double *cs = (global_double *)S.cols;
     const double cout_HI = cs[col_out(p, 0, cz)];
     const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
     const double cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
@@ -572,21 +699,47 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
       const double dist2 = xs * xs + ys * ys + zs * zs;
       vol_ph = 4.0 * pi * dist2 * path;
     }
-    if (cin_HI < max_coldensh) {
-      PhotoOut o;
-      if (MULTI) {
-        const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-        photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab, pins);
+    // photoion_rates and the sums of this cell; with_loss: also return photo_out, which the kernel otherwise never
+    // forms (one addition per band, registers that stay alive through the band loop, scalar registers short
+    // enough already: 4 % of the launch when every wave pays it) -- two copies of the code, chosen per wave below
+    auto rates_of_source = [&](auto with_loss) -> double {
+      double photo_out = 0.0;
+      if (cin_HI < max_coldensh) {
+        PhotoOut o;
+        if (MULTI) {
+          const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+          photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab, pins);
+        } else {
+          photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
+                               cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab, pins);
+        }
+        a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
+        a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);
+        a_HeII = a_HeII + o.photo_HeII / (he1 * nd * abu_he);
+        if (HEAT) a_heat = a_heat + o.heat;
+        if (decltype(with_loss)::value) photo_out = o.photo_out;
       } else {
-        photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
-                             cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab, pins);
+        // rates are zero: x + 0.0 == x
       }
-      a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
-      a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);
-      a_HeII = a_HeII + o.photo_HeII / (he1 * nd * abu_he);
-      if (HEAT) a_heat = a_heat + o.heat;
+      return photo_out;
+    };
+    // evolve_point.F90:310-315: a cell on the surface of the (final) sub-box loses photo_out * vol / vol_ph photons
+    // through it.  For a source whose last round ended for geometric reasons (SrcDev::loss_lo >= 0) that loss is
+    // the one that is kept: leave it in the cell's N_in(HI) slot, which nobody reads any more, for k_loss_stored.
+    // Only the shells of the final round count; the others were done -- and counted, for a loss that is not kept
+    // -- in earlier rounds.
+    bool surface = false;
+    if (S.loss_lo >= 0) { // uniform
+      const int ia = di < 0 ? -di : di, ja = dj < 0 ? -dj : dj, ka = dk < 0 ? -dk : dk;
+      const int shell = ia > ja ? (ia > ka ? ia : ka) : (ja > ka ? ja : ka);
+      surface = (di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] || dk == S.hi[2]) &&
+                shell >= S.loss_lo;
+    }
+    if (__any(surface ? 1 : 0)) {
+      const double photo_out = rates_of_source(std::true_type{});
+      if (surface) cs[col_in(p, 0, cz)] = photo_out * sc.vol / vol_ph;
     } else {
-      // rates are zero: x + 0.0 == x
+      (void)rates_of_source(std::false_type{});
     }
   }
   if (touched || fresh) {
@@ -996,12 +1149,29 @@ struct c2r_ctx {
   size_t list_cap = 0;             // ints per set
   double *d_loss_partial = nullptr, *d_loss_acc = nullptr;
   size_t loss_partial_cap = 0;     // doubles
-  // the sampled loss of a round is read back one round later (the sweep goes on meanwhile): two slots
-  double *d_probe_partial[2] = {nullptr, nullptr}, *d_probe_acc = nullptr, *h_probe = nullptr;
-  size_t probe_partial_cap[2] = {0, 0};
-  hipEvent_t ev_probe[2] = {nullptr, nullptr};
-  hipEvent_t ev_round[2] = {nullptr, nullptr}; // the shells a probe looks at have been queued
-  hipStream_t stream_probe = nullptr;           // probes run beside the next round's shells
+  // the sampled losses of the rounds of a batch (one entry per round and active source), read back when the
+  // sub-box loop needs them
+  double *d_probe_partial = nullptr, *d_probe_acc = nullptr, *h_probe = nullptr;
+  size_t probe_partial_cap = 0, probe_acc_cap = 0;
+  void *d_probe_rounds = nullptr, *h_probe_rounds = nullptr; // ProbeRound[probe_rounds_cap], device and pinned host
+  size_t probe_rounds_cap = 0;
+  hipEvent_t ev_probe = nullptr;  // the probes launched last, and the copy of their results, are through
+  hipEvent_t ev_round = nullptr;  // the shells those probes look at have been queued
+  hipStream_t stream_probe = nullptr;           // probes run beside the next rounds' shells
+  // losses the rates launch of a batch leaves behind (k_loss_stored), per ping-pong set
+  double *d_final_partial[2] = {nullptr, nullptr}, *d_final_acc[2] = {nullptr, nullptr}, *h_final[2] = {nullptr, nullptr};
+  size_t final_partial_cap[2] = {0, 0};
+  // per batch of the open pass, in order: what photon_loss and sum_nbox get from each of its sources
+  // (evolve_source.F90:233-236); a loss still on its way from the device is a slot of h_final[set]
+  struct BatchTail {
+    int set = 0;
+    bool resolved = false;
+    std::vector<double> loss;
+    std::vector<int> slot; // -1: `loss` holds the value
+    std::vector<int> nbox;
+  };
+  std::vector<BatchTail> tails;
+  double *h_tail = nullptr;       // pinned: photon_loss(1:47), sum_nbox on their way to the reduction buffer
   // rates launches: listed tiles, and for each the sources that reach it (CSR), per set (h: pinned)
   int *d_tiles[2] = {nullptr, nullptr}, *h_tiles[2] = {nullptr, nullptr};
   int *d_tptr[2] = {nullptr, nullptr}, *h_tptr[2] = {nullptr, nullptr};
@@ -1220,7 +1390,13 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     CR(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
     CR(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
     CR(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo));
-    CR(hipStreamCreateWithPriority(&c->stream_probe, hipStreamNonBlocking, hi));
+    {
+      // C2R_PROBE_PRIO (diagnostic): 0 = the sweep stream's (high) priority, 1 = default priority, 2 = low
+      const char *e = getenv("C2R_PROBE_PRIO");
+      const int mode = e ? atoi(e) : 0;
+      if (mode == 1) CR(hipStreamCreateWithFlags(&c->stream_probe, hipStreamNonBlocking));
+      else CR(hipStreamCreateWithPriority(&c->stream_probe, hipStreamNonBlocking, mode == 2 ? lo : hi));
+    }
     CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CR(hipEventCreateWithFlags(&c->ev_transposed, hipEventDisableTiming));
@@ -1269,10 +1445,13 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   }
   CR(hipMalloc(&c->d_loss_acc, sizeof(double) * BATCH_MAX));
   CR(hipHostMalloc(&c->h_loss, sizeof(double) * BATCH_MAX));
-  CR(hipMalloc(&c->d_probe_acc, sizeof(double) * 2 * BATCH_MAX));
-  CR(hipHostMalloc(&c->h_probe, sizeof(double) * 2 * BATCH_MAX));
-  for (int k = 0; k < 2; k++) CR(hipEventCreateWithFlags(&c->ev_probe[k], hipEventDisableTiming));
-  for (int k = 0; k < 2; k++) CR(hipEventCreateWithFlags(&c->ev_round[k], hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&c->ev_probe, hipEventDisableTiming));
+  CR(hipEventCreateWithFlags(&c->ev_round, hipEventDisableTiming));
+  for (int k = 0; k < 2; k++) {
+    CR(hipMalloc(&c->d_final_acc[k], sizeof(double) * BATCH_MAX));
+    CR(hipHostMalloc(&c->h_final[k], sizeof(double) * BATCH_MAX));
+  }
+  CR(hipHostMalloc(&c->h_tail, sizeof(double) * (C2R_NFREQ + 1)));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
   CR(hipHostMalloc(&c->h_conv, sizeof(int)));
   CR(hipMalloc(&c->d_bands, sizeof(BandData)));
@@ -1306,10 +1485,16 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (sg.p) (void)hipFree(sg.p);
   if (c->h_loss) (void)hipHostFree(c->h_loss);
   if (c->h_probe) (void)hipHostFree(c->h_probe);
+  if (c->h_tail) (void)hipHostFree(c->h_tail);
+  if (c->d_probe_partial) (void)hipFree(c->d_probe_partial);
+  if (c->d_probe_rounds) (void)hipFree(c->d_probe_rounds);
+  if (c->h_probe_rounds) (void)hipHostFree(c->h_probe_rounds);
+  if (c->ev_probe) (void)hipEventDestroy(c->ev_probe);
+  if (c->ev_round) (void)hipEventDestroy(c->ev_round);
   for (int k = 0; k < 2; k++) {
-    if (c->d_probe_partial[k]) (void)hipFree(c->d_probe_partial[k]);
-    if (c->ev_probe[k]) (void)hipEventDestroy(c->ev_probe[k]);
-    if (c->ev_round[k]) (void)hipEventDestroy(c->ev_round[k]);
+    if (c->d_final_partial[k]) (void)hipFree(c->d_final_partial[k]);
+    if (c->d_final_acc[k]) (void)hipFree(c->d_final_acc[k]);
+    if (c->h_final[k]) (void)hipHostFree(c->h_final[k]);
   }
   if (c->d_probe_acc) (void)hipFree(c->d_probe_acc);
   for (int k = 0; k < 2; k++) {
@@ -1890,38 +2075,80 @@ constexpr int TRANSPOSED_FROM_SHELL = C2R_TRANSPOSED_FROM_SHELL;
 
 constexpr int PROBE_SAMPLE = 16; // the probe looks at 8 cells of every 16th block of the round's shells
 
-// Queue the probe of the round's loss for the sources d_list[set][list_off .. +n) into slot `slot` (results in
-// c->h_probe + slot * BATCH_MAX once c->ev_probe[slot] has happened).  Does not wait.  The probe runs on its own
-// stream behind the shells queued so far, so that the next round's shells (which only read what the probe reads)
-// need not queue behind its two small kernels and the copy of their result: ~22 us per round on the sweep stream.
-// Whoever then changes what a probe reads -- the SrcDev entries, when a block moves -- waits for ev_probe first.
-static int launch_probe(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, int s_hi, const Box &box, int slot,
-                        const StepScalars &sc, const SedSet &ss, bool multi) {
-  const int count = c->block_base[s_hi + 1] - c->block_base[s_lo];
-  const int nblk = (count + PROBE_SAMPLE - 1) / PROBE_SAMPLE;
-  const size_t need = (size_t)nblk * n;
-  if (c->probe_partial_cap[slot] < need) {
-    HIPCHK(c, hipStreamSynchronize(c->stream_probe));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ensure_pair<double>(c, &c->d_probe_partial[slot], (double **)nullptr, &c->probe_partial_cap[slot], need)) return 1;
+// One round of a batch's sub-box loop, as the probes and the while-test see it.
+struct RoundRec {
+  int round = 0, nact = 0, s_lo = 0, s_hi = 0;
+  size_t off = 0;     // its active list in h_list / d_list
+  size_t acc_off = 0; // its results in d_probe_acc / h_probe
+  Box box{};
+};
+
+// Queue the probes of the rounds recs[from .. to) (lower bounds of their boundary losses, k_loss_probe) on the probe
+// stream, behind everything queued on the sweep stream so far, and the copy of all their results to h_probe; ev_probe
+// marks the end.  Does not wait.  One event on the sweep stream for all of them: the rounds of a batch whose
+// sources are all expected to go on (prev_nbox) are probed together, late, and the sweep stream sees no probe
+// kernel, no copy and no other event between its shells.  Whoever then changes what a probe reads -- the SrcDev
+// entries, when a block moves -- waits for ev_probe first.
+static int launch_probes(c2r_ctx *c, int set, const std::vector<RoundRec> &recs, size_t from, size_t to, const StepScalars &sc,
+                         const SedSet &ss, bool multi) {
+  if (from >= to) return 0;
+  size_t need = 0;
+  for (size_t i = from; i < to; i++) {
+    const int count = c->block_base[recs[i].s_hi + 1] - c->block_base[recs[i].s_lo];
+    need += (size_t)((count + PROBE_SAMPLE - 1) / PROBE_SAMPLE) * (size_t)recs[i].nact;
+  }
+  const size_t acc_need = recs[to - 1].acc_off + (size_t)recs[to - 1].nact;
+  HIPCHK(c, hipEventSynchronize(c->ev_probe)); // the descriptors of an earlier launch have left the pinned buffer
+  if (c->probe_acc_cap < acc_need) return fail(c, "internal: probe results of %zu rounds do not fit (%zu > %zu)", to, acc_need, c->probe_acc_cap);
+  if (c->probe_partial_cap < need) {
+    HIPCHK(c, hipStreamSynchronize(c->stream_probe)); // earlier probes may still use the old buffer
+    if (ensure_pair<double>(c, &c->d_probe_partial, (double **)nullptr, &c->probe_partial_cap, need)) return 1;
   }
 #ifdef C2R_PROBE_INLINE
   hipStream_t st = c->stream;
 #else
   hipStream_t st = c->stream_probe;
-  HIPCHK(c, hipEventRecord(c->ev_round[slot], c->stream));
-  HIPCHK(c, hipStreamWaitEvent(st, c->ev_round[slot], 0));
+  HIPCHK(c, hipEventRecord(c->ev_round, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(st, c->ev_round, 0));
 #endif
-  hipLaunchKernelGGL(k_loss_probe, dim3(nblk, n), dim3(BLOCK), 0, st, c->g, c->d_src[set], c->d_list[set] + list_off,
-                     multi ? 1 : 0, s_lo, s_hi, box, sc, c->d_bands, ss, c->d_block_base, c->d_probe_partial[slot], nblk,
-                     PROBE_SAMPLE);
-  hipLaunchKernelGGL(k_loss_finish, dim3(n), dim3(BLOCK), 0, st, c->d_probe_partial[slot], nblk, nblk,
-                     c->d_probe_acc + (size_t)slot * BATCH_MAX);
+  // descriptors of the rounds, then one probe launch and one finishing launch for all of them
+  const size_t nr = to - from;
+  if (c->probe_rounds_cap < nr) {
+    HIPCHK(c, hipStreamSynchronize(c->stream_probe));
+    if (c->d_probe_rounds) HIPCHK(c, hipFree(c->d_probe_rounds));
+    if (c->h_probe_rounds) HIPCHK(c, hipHostFree(c->h_probe_rounds));
+    c->d_probe_rounds = c->h_probe_rounds = nullptr;
+    const size_t want = nr + 64;
+    HIPCHK(c, hipMalloc(&c->d_probe_rounds, sizeof(ProbeRound) * want));
+    HIPCHK(c, hipHostMalloc(&c->h_probe_rounds, sizeof(ProbeRound) * want));
+    c->probe_rounds_cap = want;
+  }
+  ProbeRound *hr = static_cast<ProbeRound *>(c->h_probe_rounds);
+  size_t used = 0;
+  int max_nblk = 0, max_nact = 0;
+  for (size_t i = from; i < to; i++) {
+    const RoundRec &R = recs[i];
+    const int count = c->block_base[R.s_hi + 1] - c->block_base[R.s_lo];
+    ProbeRound &P = hr[i - from];
+    P.s_lo = R.s_lo; P.s_hi = R.s_hi; P.box = R.box;
+    P.list_off = (int)R.off; P.nact = R.nact;
+    P.nblk = (count + PROBE_SAMPLE - 1) / PROBE_SAMPLE;
+    P.partial_off = (int)used; P.acc_off = (int)R.acc_off;
+    used += (size_t)P.nblk * (size_t)R.nact;
+    max_nblk = std::max(max_nblk, P.nblk);
+    max_nact = std::max(max_nact, P.nact);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_probe_rounds, hr, sizeof(ProbeRound) * nr, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_loss_probe_rounds, dim3(max_nblk, max_nact, (unsigned)nr), dim3(BLOCK), 0, st, c->g, c->d_src[set], c->d_list[set],
+                     static_cast<const ProbeRound *>(c->d_probe_rounds), multi ? 1 : 0, sc, c->d_bands, ss, c->d_block_base,
+                     c->d_probe_partial, PROBE_SAMPLE);
+  hipLaunchKernelGGL(k_loss_finish_rounds, dim3(max_nact, (unsigned)nr), dim3(BLOCK), 0, st,
+                     static_cast<const ProbeRound *>(c->d_probe_rounds), c->d_probe_partial, c->d_probe_acc);
   c->tm.sweep_launches += 2;
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_probe + (size_t)slot * BATCH_MAX, c->d_probe_acc + (size_t)slot * BATCH_MAX, sizeof(double) * n,
-                           hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipEventRecord(c->ev_probe[slot], st));
+  const size_t a0 = recs[from].acc_off;
+  HIPCHK(c, hipMemcpyAsync(c->h_probe + a0, c->d_probe_acc + a0, sizeof(double) * (acc_need - a0), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(c->ev_probe, st));
   return 0;
 }
 
@@ -1932,6 +2159,17 @@ static int launch_probe(c2r_ctx *c, int set, size_t list_off, int n, int s_lo, i
 // so the accumulation over sources keeps the reference's order.
 static int pass_finish(c2r_ctx *c);
 static int flush_rates_zero(c2r_ctx *c);
+
+// the losses of set `set`'s batches that were still on their way from the device (the caller has waited for the
+// set's last rates launch and what follows it)
+static void resolve_tails(c2r_ctx *c, int set) {
+  for (c2r_ctx::BatchTail &bt : c->tails) {
+    if (bt.resolved || bt.set != set) continue;
+    for (size_t b = 0; b < bt.loss.size(); b++)
+      if (bt.slot[b] >= 0) bt.loss[b] = c->h_final[set][bt.slot[b]];
+    bt.resolved = true;
+  }
+}
 
 // nslab > 0: the caller wants to consume the rate grids slab by slab (z ranges) while later slabs are
 // still being computed: the rates launch of the LAST batch is cut into nslab launches, an event is
@@ -1997,6 +2235,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     if (c->set_busy[set]) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[set], 0));
       HIPCHK(c, hipEventSynchronize(c->ev_rates_done[set]));
+      resolve_tails(c, set); // h_final[set] is about to be written again
     }
     std::vector<SrcRun> run;
   restart_batch:
@@ -2067,61 +2306,82 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     size_t list_used = 0;
     long long batch_cells = 0;
     int *hl = c->h_list[set];
-    // The sub-box loop (evolve_source.F90:136-144), pipelined one round deep.  After the shells of round r a probe of
-    // the round's boundary loss is queued, but its result is only needed to know who sweeps round r+1.  When every
-    // active source went beyond round r in the previous pass (prev_nbox), round r+1 is launched at once for all of
-    // them and the probe is read afterwards, while those shells run: the device never waits for the host.  A
-    // source that turns out to have stopped at r keeps round r as its last -- its shells of round r+1 are
-    // never looked at (the rates launch only sees the final box), so a wrong guess costs time, never a bit.
-    struct Pending { // a probe in flight
-      bool on = false;
-      int round = 0, slot = 0, nact = 0, s_lo = 0, s_hi = 0;
-      size_t off = 0;
-      Box box{};
-    } pend;
-    // read a probe, replace what it leaves undecided by the full sum, apply the while-test: sources that stop get
-    // active = false and the round as their last
-    auto settle = [&](Pending &P) -> int {
-      if (!P.on) return 0;
-      P.on = false;
-      HIPCHK(c, hipEventSynchronize(c->ev_probe[P.slot]));
-      const double *probe = c->h_probe + (size_t)P.slot * BATCH_MAX;
-      const int *lst = hl + P.off;
-      std::vector<int> undecided;
-      for (int a = 0; a < P.nact; a++) {
-        SrcRun &r = run[lst[a]];
-        if (!r.active) continue; // stopped at an earlier round: swept this one on trust, to no effect
-        r.loss = probe[a];
-        if (!(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) undecided.push_back(lst[a]);
+    // The sub-box loop (evolve_source.F90:136-144).  After the shells of round r the loss through the box surface
+    // decides who sweeps round r+1; a quick lower bound of it (k_loss_probe) nearly always does.  When every active
+    // source went beyond round r in the previous pass (prev_nbox), round r+1 is launched at once for all of them, on
+    // trust, and the probe of round r is not even queued yet: the probes of all such rounds go out together, on
+    // their own stream, when a decision is really needed -- before a round that some source did not reach last time,
+    // or before the round that is everybody's last for geometric reasons -- so that the sweep stream carries shells
+    // and nothing else (a probe per round cost it an event, and 13-24 us of gap at each of the 12 round boundaries
+    // of a 256^3 sweep).  A source that turns out to have stopped at r keeps round r as its last -- its shells
+    // of later rounds are never looked at (the rates launch only sees the final box), so a wrong guess costs time,
+    // never a bit.
+    std::vector<RoundRec> recs;       // the rounds swept so far
+    size_t settled = 0, launched = 0; // recs[0, settled): while-test applied; recs[settled, launched): probes in flight
+    {
+      const size_t acc_need = (size_t)nb * (size_t)(g.smax / SUBBOXSIZE + 3);
+      if (c->probe_acc_cap < acc_need) {
+        HIPCHK(c, hipStreamSynchronize(c->stream_probe));
+        if (ensure_pair<double>(c, &c->d_probe_acc, &c->h_probe, &c->probe_acc_cap, acc_need)) return 1;
       }
-      if (!undecided.empty()) {
-        int *ul = hl + list_used;
-        std::copy(undecided.begin(), undecided.end(), ul);
-        HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, ul, sizeof(int) * undecided.size(), hipMemcpyHostToDevice, c->stream));
-        if (boundary_loss(c, set, list_used, (int)undecided.size(), P.s_lo, P.s_hi, P.box, 1, sc, ss, multi)) return 1;
-        list_used += undecided.size();
-        for (size_t j = 0; j < undecided.size(); j++) run[undecided[j]].loss = c->h_loss[j];
-      }
-      for (int a = 0; a < P.nact; a++) {
-        SrcRun &r = run[lst[a]];
-        if (!r.active) continue;
-        if (!(r.loss > C2R_F(1e-10) * r.total_flux)) { // evolve_source.F90:136: the box does not grow any more
-          r.active = false;
-          r.nbox = P.round;
+    }
+    auto launch = [&]() -> int {
+      if (launch_probes(c, set, recs, launched, recs.size(), sc, ss, multi)) return 1;
+      launched = recs.size();
+      return 0;
+    };
+    // read the probes of all rounds not yet decided, replace what a probe leaves undecided by the full sum, apply
+    // the while-test round by round: sources that stop get active = false and that round as their last
+    auto settle = [&]() -> int {
+      if (settled == recs.size()) return 0;
+      if (launch()) return 1;
+      HIPCHK(c, hipEventSynchronize(c->ev_probe));
+      for (; settled < recs.size(); settled++) {
+        const RoundRec &P = recs[settled];
+        const double *probe = c->h_probe + P.acc_off;
+        const int *lst = hl + P.off;
+        std::vector<int> undecided;
+        for (int a = 0; a < P.nact; a++) {
+          SrcRun &r = run[lst[a]];
+          if (!r.active) continue; // stopped at an earlier round: swept this one on trust, to no effect
+          r.loss = probe[a];
+          if (!(r.loss > 2.0 * (C2R_F(1e-10) * r.total_flux))) undecided.push_back(lst[a]);
+        }
+        if (!undecided.empty()) {
+          int *ul = hl + list_used;
+          std::copy(undecided.begin(), undecided.end(), ul);
+          HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, ul, sizeof(int) * undecided.size(), hipMemcpyHostToDevice, c->stream));
+          if (boundary_loss(c, set, list_used, (int)undecided.size(), P.s_lo, P.s_hi, P.box, 1, sc, ss, multi)) return 1;
+          list_used += undecided.size();
+          for (size_t j = 0; j < undecided.size(); j++) run[undecided[j]].loss = c->h_loss[j];
+        }
+        for (int a = 0; a < P.nact; a++) {
+          SrcRun &r = run[lst[a]];
+          if (!r.active) continue;
+          if (!(r.loss > C2R_F(1e-10) * r.total_flux)) { // evolve_source.F90:136: the box does not grow any more
+            r.active = false;
+            r.nbox = P.round;
+          }
         }
       }
       return 0;
     };
+    // every source still active reached at least round `round` in the previous pass
+    auto all_reached = [&](int round) {
+      bool yes = true;
+      for (int b = 0; b < nb && yes; b++)
+        if (run[b].active) yes = c->prev_nbox[(size_t)run[b].ns - 1] >= round;
+      return yes;
+    };
     size_t cur_off = 0; // the active list of the last round launched
     int cur_nact = 0;
+    size_t acc_used = 0;
     for (int round = 1;; round++) {
       const Box box = round_box(reach, round);
       const int s_hi = box_smax(box);
-      // may this round start before the previous round's probe has been read?
-      bool ahead = pend.on && cur_nact > 0;
-      if (ahead)
-        for (int a = 0; a < cur_nact && ahead; a++) ahead = c->prev_nbox[(size_t)run[hl[cur_off + a]].ns - 1] >= round;
-      if (!ahead && settle(pend)) return 1;
+      // may this round start before the losses of the rounds before it are known?
+      const bool ahead = round > 1 && cur_nact > 0 && all_reached(round);
+      if (!ahead && settle()) return 1;
       // who sweeps this round: the while-test of evolve_source.F90:136-139 (its loss part taken on trust when ahead)
       int nact = 0;
       int *act = hl + list_used;
@@ -2138,7 +2398,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         s_lo = std::min(s_lo, r.smax_prev + 1);
       }
       if (nact == 0) {
-        if (settle(pend)) return 1;
+        if (settle()) return 1;
         break;
       }
       if (s_hi > g.smax) return fail(c, "internal: shell %d beyond smax %d", s_hi, g.smax);
@@ -2165,8 +2425,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           nb = (nb + 1) / 2;
           goto restart_batch;
         }
-        // a probe in flight reads this source's SrcDev entry: it must be through before the entry changes
-        if (pend.on) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_probe[pend.slot], 0));
+        // probes in flight read this source's SrcDev entry: they must be through before the entry changes
+        if (launched > settled) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_probe, 0));
         SrcDev &S = c->h_src[set][act[a]];
         const size_t wn = (size_t)(2 * ncap + 1), ncz = wn * wn * wn;
         const size_t wp = (size_t)(2 * r.smax_prev + 1), have = r.smax_prev >= 0 ? wp * wp * wp : 0;
@@ -2210,12 +2470,11 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       }
       HIPCHK(c, hipGetLastError());
       for (int a = 0; a < nact; a++) run[hl[act_off + a]].smax_prev = s_hi;
-      // the probe of the round before, if this round went ahead of it: sources it stops keep that round as their
-      // last (and drop out of the lists from the next round on)
-      if (settle(pend)) return 1;
       if (!box_can_grow(reach, box)) {
         // The while-test after this round fails whatever the loss: the round is every active source's last, and
-        // its loss (the one that is kept, evolve_source.F90:233) is evaluated after the sweep, beside the rates.
+        // its loss (the one that is kept, evolve_source.F90:233) comes out of the rates launch (SrcDev::loss_lo).
+        // The rounds before it are decided now; their probes were queued before this round's shells.
+        if (settle()) return 1;
         for (int a = 0; a < nact; a++) {
           SrcRun &r = run[hl[act_off + a]];
           if (!r.active) continue; // stopped a round earlier after all
@@ -2224,19 +2483,25 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         }
         break;
       }
-      // The loss of this round decides whether a source goes on: queue its probe, read it in the next round.
-      pend.on = true;
-      pend.round = round;
-      pend.slot = round & 1;
-      pend.nact = nact;
-      pend.s_lo = s_lo;
-      pend.s_hi = s_hi;
-      pend.off = act_off;
-      pend.box = box;
-      if (launch_probe(c, set, act_off, nact, s_lo, s_hi, box, pend.slot, sc, ss, multi)) return 1;
+      // The loss of this round decides whether a source goes on.
+      RoundRec R;
+      R.round = round; R.nact = nact; R.s_lo = s_lo; R.s_hi = s_hi; R.off = act_off; R.acc_off = acc_used; R.box = box;
+      acc_used += (size_t)nact;
+      recs.push_back(R);
+      // Its probe goes out now if the next round needs the answer before it can start (somebody may stop here) or if
+      // the next round is the last for geometric reasons (the probes then run beside its shells, and the answers
+      // are there when the rates launch has to be put together); otherwise it waits for company.
+      const bool next_is_last = !box_can_grow(reach, round_box(reach, round + 1));
+      // C2R_PROBE_EACH_ROUND=1 (diagnostic): queue every round's probe right behind its shells
+      static const bool each_round = getenv("C2R_PROBE_EACH_ROUND") && atoi(getenv("C2R_PROBE_EACH_ROUND")) > 0;
+      if ((each_round || !all_reached(round + 1) || next_is_last) && launch()) return 1;
     }
     for (int b = 0; b < nb; b++) batch_cells += run[b].nbox > 0 ? box_cells(round_box(reach, run[b].nbox)) : 0;
     // final sub-boxes for the rates launch
+    bool any_final = false;
+    // C2R_FINAL_LOSS_KERNEL=1 (diagnostic): evaluate the kept losses of final rounds with k_loss, beside the rates
+    // launch, as rounds 1 and 2 of this library did, instead of taking them from the rates launch
+    static const bool legacy_final_loss = getenv("C2R_FINAL_LOSS_KERNEL") && atoi(getenv("C2R_FINAL_LOSS_KERNEL")) > 0;
     for (int b = 0; b < nb; b++) {
       SrcDev &S = c->h_src[set][b];
       const Box fb = round_box(reach, run[b].nbox);
@@ -2244,6 +2509,13 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       // a source whose while-test failed before the first sub-box (a mesh only two cells deep) traced nothing:
       // an empty box, so that no cell passes the in-box test
       if (run[b].nbox == 0) { S.lo[0] = 1; S.hi[0] = 0; }
+      // the kept loss of a round that was the last for geometric reasons comes out of the rates launch: the
+      // surface cells in the shells of that round
+      S.loss_lo = -1;
+      if (run[b].final_loss_due && !legacy_final_loss) {
+        any_final = true;
+        S.loss_lo = run[b].nbox > 1 ? box_smax(round_box(reach, run[b].nbox - 1)) + 1 : 0;
+      }
       c->prev_nbox[(size_t)run[b].ns - 1] = run[b].nbox;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_src[set], c->h_src[set], sizeof(SrcDev) * nb, hipMemcpyHostToDevice, c->stream));
@@ -2402,35 +2674,84 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       HIPCHK(c, hipEventRecord(e_r1, c->stream2));
       tev.push_back(e_s0); tev.push_back(e_s1); tev.push_back(e_r0); tev.push_back(e_r1);
     }
+    // The losses that are kept but decided nothing (rounds that were a source's last for geometric reasons): the
+    // rates launch has left their terms in the column blocks; add them up behind it, on its stream, one launch per
+    // final round (the same for every source of a mesh, so one launch), and send the sums to the host.
+    c2r_ctx::BatchTail bt;
+    bt.set = set;
+    bt.loss.resize((size_t)nb);
+    bt.slot.assign((size_t)nb, -1);
+    bt.nbox.resize((size_t)nb);
+    for (int b = 0; b < nb; b++) {
+      bt.loss[(size_t)b] = run[b].loss;
+      bt.nbox[(size_t)b] = run[b].nbox;
+    }
+    if (any_final) {
+      int nslot = 0;
+      for (;;) {
+        int fr = -1;
+        for (int b = 0; b < nb; b++)
+          if (run[b].final_loss_due) { fr = run[b].nbox; break; }
+        if (fr < 0) break;
+        int *fl = hl + list_used;
+        int nf = 0;
+        for (int b = 0; b < nb; b++)
+          if (run[b].final_loss_due && run[b].nbox == fr) {
+            bt.slot[(size_t)b] = nslot + nf;
+            fl[nf++] = b;
+            run[b].final_loss_due = false;
+          }
+        HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, fl, sizeof(int) * nf, hipMemcpyHostToDevice, c->stream2));
+        const Box fb = round_box(reach, fr);
+        const int f_lo = fr > 1 ? box_smax(round_box(reach, fr - 1)) + 1 : 0, f_hi = box_smax(fb);
+        const int nblk_l = c->block_base[f_hi + 1] - c->block_base[f_lo];
+        const size_t need = (size_t)nblk_l * (size_t)nf;
+        if (c->final_partial_cap[set] < need) {
+          HIPCHK(c, hipStreamSynchronize(c->stream2));
+          if (ensure_pair<double>(c, &c->d_final_partial[set], (double **)nullptr, &c->final_partial_cap[set], need)) return 1;
+        }
+        // a surface cell has one coordinate on a face of the box, so its shell is at least the nearest face's
+        // distance: the shells before that hold none, their blocks are not launched and their partial sums are zero
+        int s_first = 1 << 30;
+        for (int d = 0; d < 3; d++) s_first = std::min(s_first, std::min(std::abs(fb.lo[d]), std::abs(fb.hi[d])));
+        s_first = std::min(std::max(s_first, f_lo), f_hi);
+        const int first_block = c->block_base[s_first] - c->block_base[f_lo];
+        if (first_block > 0) HIPCHK(c, zero_device(c->d_final_partial[set], sizeof(double) * need, c->stream2));
+        hipLaunchKernelGGL(k_loss_stored, dim3(nblk_l - first_block, nf), dim3(BLOCK), 0, c->stream2, c->g, c->d_src[set],
+                           c->d_list[set] + list_used, f_lo, f_hi, fb, c->d_block_base, c->d_final_partial[set], nblk_l, first_block);
+        hipLaunchKernelGGL(k_loss_finish, dim3(nf), dim3(BLOCK), 0, c->stream2, c->d_final_partial[set], nblk_l, nblk_l,
+                           c->d_final_acc[set] + nslot);
+        HIPCHK(c, hipGetLastError());
+        list_used += (size_t)nf;
+        nslot += nf;
+      }
+      HIPCHK(c, hipMemcpyAsync(c->h_final[set], c->d_final_acc[set], sizeof(double) * nslot, hipMemcpyDeviceToHost, c->stream2));
+    } else {
+      if (legacy_final_loss)
+        for (;;) {
+          int fr = -1;
+          for (int b = 0; b < nb; b++)
+            if (run[b].final_loss_due) { fr = run[b].nbox; break; }
+          if (fr < 0) break;
+          int *fl = hl + list_used;
+          int nf = 0;
+          for (int b = 0; b < nb; b++)
+            if (run[b].final_loss_due && run[b].nbox == fr) fl[nf++] = b;
+          HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, fl, sizeof(int) * nf, hipMemcpyHostToDevice, c->stream));
+          const Box fb = round_box(reach, fr);
+          const int f_lo = fr > 1 ? box_smax(round_box(reach, fr - 1)) + 1 : 0;
+          if (boundary_loss(c, set, list_used, nf, f_lo, box_smax(fb), fb, 1, sc, ss, multi)) return 1;
+          for (int j = 0; j < nf; j++) {
+            bt.loss[(size_t)fl[j]] = c->h_loss[j];
+            run[fl[j]].final_loss_due = false;
+          }
+          list_used += (size_t)nf;
+        }
+      bt.resolved = true;
+    }
+    c->tails.push_back(std::move(bt));
     HIPCHK(c, hipEventRecord(c->ev_rates_done[set], c->stream2));
     c->set_busy[set] = true;
-
-    // The losses that are kept but decided nothing (rounds that were a source's last for geometric reasons),
-    // one launch per final round, on the sweep stream while the rates run on theirs.
-    for (;;) {
-      int fr = -1;
-      for (int b = 0; b < nb; b++)
-        if (run[b].final_loss_due) { fr = run[b].nbox; break; }
-      if (fr < 0) break;
-      int *fl = hl + list_used;
-      int nf = 0;
-      for (int b = 0; b < nb; b++)
-        if (run[b].final_loss_due && run[b].nbox == fr) fl[nf++] = b;
-      HIPCHK(c, hipMemcpyAsync(c->d_list[set] + list_used, fl, sizeof(int) * nf, hipMemcpyHostToDevice, c->stream));
-      const Box fb = round_box(reach, fr);
-      const int f_lo = fr > 1 ? box_smax(round_box(reach, fr - 1)) + 1 : 0;
-      if (boundary_loss(c, set, list_used, nf, f_lo, box_smax(fb), fb, 1, sc, ss, multi)) return 1;
-      for (int j = 0; j < nf; j++) {
-        run[fl[j]].loss = c->h_loss[j];
-        run[fl[j]].final_loss_due = false;
-      }
-      list_used += (size_t)nf;
-    }
-    // photon_loss(1) += photon_loss_src ; sum_nbox += nbox  (evolve_source.F90:233-236), source order
-    for (int b = 0; b < nb; b++) {
-      c->photon_loss[0] = c->photon_loss[0] + run[b].loss;
-      c->sum_nbox += run[b].nbox;
-    }
     c->tm.cells_swept += batch_cells;
     c->last_src = run[nb - 1].ns;
     c->last_cols = c->h_src[set][nb - 1].cols;
@@ -2445,11 +2766,6 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   // a rank without sources of its own still owes the caller its slab events
   if (mine.empty())
     for (int sidx = 0; sidx < ns_eff; sidx++) HIPCHK(c, hipEventRecord(c->ev_slab[sidx], c->stream2));
-  // tail of the reduction buffer: photon_loss(1:47), sum_nbox
-  double tail[C2R_NFREQ + 1];
-  std::memcpy(tail, c->photon_loss, sizeof c->photon_loss);
-  tail[C2R_NFREQ] = (double)c->sum_nbox;
-  HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * nc, tail, sizeof tail, hipMemcpyHostToDevice, c->stream));
   c->pass_tev = tev;
   c->pass_open = true;
   c->pass_slabs = ns_eff;
@@ -2462,6 +2778,21 @@ static int pass_finish(c2r_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream2));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->set_busy[0] = c->set_busy[1] = false;
+  // photon_loss(1) += photon_loss_src ; sum_nbox += nbox  (evolve_source.F90:233-236): batch by batch, source by
+  // source, now that the losses the rates launches left behind have arrived
+  resolve_tails(c, 0);
+  resolve_tails(c, 1);
+  for (const c2r_ctx::BatchTail &bt : c->tails)
+    for (size_t b = 0; b < bt.loss.size(); b++) {
+      c->photon_loss[0] = c->photon_loss[0] + bt.loss[b];
+      c->sum_nbox += bt.nbox[b];
+    }
+  c->tails.clear();
+  // tail of the reduction buffer: photon_loss(1:47), sum_nbox
+  std::memcpy(c->h_tail, c->photon_loss, sizeof c->photon_loss);
+  c->h_tail[C2R_NFREQ] = (double)c->sum_nbox;
+  HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * c->g.ncell, c->h_tail, sizeof(double) * (C2R_NFREQ + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   const std::vector<hipEvent_t> &tev = c->pass_tev;
   for (size_t i = 0; i + 3 < tev.size(); i += 4) {
     float ms = 0;
