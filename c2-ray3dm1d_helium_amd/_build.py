@@ -10,7 +10,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libc2ray_hip.so"
 SOURCES = [CSRC / "c2ray_hip.hip"]
-HEADERS = [CSRC / "c2ray_device.hpp", CSRC / "c2ray_math.hpp", CSRC / "c2ray_math_tables.hpp", CSRC / "c2ray_comm.inc",
+HEADERS = [CSRC / "c2ray_device.hpp", CSRC / "c2ray_shell.hpp", CSRC / "c2ray_math.hpp", CSRC / "c2ray_math_tables.hpp", CSRC / "c2ray_comm.inc",
            PKG.parent / "include" / "c2ray_hip.h"]
 # -ffp-contract=off: the reference's flang -O2 x86-64 build performs no FMA contraction; fusing
 # a*b+c on the GPU changes results in the last bit, which the outer iteration amplifies.

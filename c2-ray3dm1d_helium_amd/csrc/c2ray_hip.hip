@@ -28,6 +28,7 @@
 
 #include "../../include/c2ray_hip.h"
 #include "c2ray_device.hpp"
+#include "c2ray_shell.hpp"
 
 using namespace c2r;
 
@@ -79,54 +80,6 @@ __device__ __forceinline__ int wrap0(int x, int n) { // 0-based periodic index o
 __device__ __forceinline__ size_t cell_index(const Grid &g, int i0, int j0, int k0, int di, int dj, int dk) {
   int i = wrap0(i0 - 1 + di, g.n1), j = wrap0(j0 - 1 + dj, g.n2), k = wrap0(k0 - 1 + dk, g.n3);
   return (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
-}
-
-// number of cells of the L-infinity shell s
-__host__ __device__ inline long long shell_count(int s) { return s == 0 ? 1 : 24LL * s * s + 2; }
-
-// first entry of shell s in a shell-ordered array: the (2s-1)^3 cells of all smaller shells come first
-__host__ __device__ inline long long shell_offset(int s) {
-  return s == 0 ? 0 : (long long)(2 * s - 1) * (2 * s - 1) * (2 * s - 1);
-}
-
-// t in [0, shell_count(s)) -> offset (di,dj,dk) with max(|di|,|dj|,|dk|) == s; i runs fastest on
-// the k- and j-faces so that consecutive lanes touch consecutive memory there.
-__device__ __forceinline__ void shell_decode(int s, int t, int &di, int &dj, int &dk) {
-  if (s == 0) { di = dj = dk = 0; return; }
-  const int w = 2 * s + 1, v = 2 * s - 1;
-  const int A = w * w, B = v * w, C = v * v;
-  if (t < 2 * A) {
-    dk = t < A ? s : -s;
-    if (t >= A) t -= A;
-    dj = t / w - s;
-    di = t % w - s;
-  } else if (t < 2 * A + 2 * B) {
-    t -= 2 * A;
-    dj = t < B ? s : -s;
-    if (t >= B) t -= B;
-    dk = t / w - (s - 1);
-    di = t % w - s;
-  } else {
-    t -= 2 * A + 2 * B;
-    di = t < C ? s : -s;
-    if (t >= C) t -= C;
-    dk = t / v - (s - 1);
-    dj = t % v - (s - 1);
-  }
-}
-
-// inverse of shell_decode: position of the cell at offset (di,dj,dk) in a shell-ordered array
-__device__ __forceinline__ size_t shell_position(int di, int dj, int dk) {
-  const int ia = di < 0 ? -di : di, ja = dj < 0 ? -dj : dj, ka = dk < 0 ? -dk : dk;
-  const int s = ia > ja ? (ia > ka ? ia : ka) : (ja > ka ? ja : ka);
-  if (s == 0) return 0;
-  const int w = 2 * s + 1, v = 2 * s - 1;
-  const int A = w * w, B = v * w, C = v * v;
-  int t;
-  if (ka == s) t = (dk > 0 ? 0 : A) + (dj + s) * w + (di + s);
-  else if (ja == s) t = 2 * A + (dj > 0 ? 0 : B) + (dk + s - 1) * w + (di + s);
-  else t = 2 * A + 2 * B + (di > 0 ? 0 : C) + (dk + s - 1) * v + (dj + s - 1);
-  return (size_t)shell_offset(s) + (size_t)t;
 }
 
 __device__ __forceinline__ double block_sum(double x, double *sh) {
@@ -457,6 +410,78 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
           lls_grid ? (double)lls_grid[cell_index(g, S.i0, S.j0, S.k0, di, dj, dk)] : sc.coldensh_lls;
       cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
     }
+  }
+  const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
+  const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
+  const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
+  cs[col_in(p, 0, cz)] = cin_HI;
+  cs[col_in(p, 1, cz)] = cin_HeI;
+  cs[col_in(p, 2, cz)] = cin_HeII;
+  cs[col_out(p, 0, cz)] = cout_HI;
+  cs[col_out(p, 1, cz)] = cout_HeI;
+  cs[col_out(p, 2, cz)] = cout_HeII;
+}
+
+// The same for a shell s >= 2, with everything that is common to the cells of one shell taken out of the cell's
+// work (ShellGeom, c2ray_shell.hpp): no integer division in the thread -> cell map, cinterp's alam as a per-launch
+// constant, the path's division by s^2 as three fma, the 12 reciprocals of weightf without the division's operand
+// scaling, and the corners' positions from the face formulas of shell s-1 instead of four general inverse maps
+// (corners of weight exactly 0 on the edges of a face are read from the nearest cell of shell s-1).  Bit for bit
+// the columns of k_sweep_shell (tests: C2R_SWEEP_GENERIC=1 runs that one for every shell).
+__global__ void __launch_bounds__(BLOCK, C2R_SWEEP_WAVES)
+k_sweep_shell_fast(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ active, ShellGeom G, Box box, StepScalars sc,
+                   const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
+                   const double *__restrict__ stateT, const float *__restrict__ lls_grid) {
+  const SrcDev &S = src[active[blockIdx.y]];
+  const int cnt = 24 * G.s * G.s + 2;
+  // blocks of one XCD (equal blockIdx.x mod 8) take one contiguous eighth of the shell (see k_sweep_shell)
+  const int nblk_shell = (cnt + BLOCK - 1) / BLOCK;
+  int vb = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0) {
+    const int chunk = (int)gridDim.x >> 3;
+    vb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  }
+  if (vb >= nblk_shell) return;
+  const int t = vb * BLOCK + (int)threadIdx.x;
+  if (t >= cnt) return;
+  int di, dj, dk;
+  const int face = shell_decode_fast(G, t, di, dj, dk);
+  const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
+                      dk <= box.hi[2];
+  if (!inside) return;
+  const size_t nc = g.ncell, cz = S.cz;
+  const size_t p = (size_t)G.off + (size_t)t;
+  global_double *cs = (global_double *)S.cols;
+  const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
+  double nd, h0, he0, he1;
+  if (stateT && face == 2) {
+    // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies
+    const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
+    nd = stateT[qT];
+    h0 = dmax(stateT[qT + nc], epsilon);
+    he0 = dmax(stateT[qT + 2 * nc], epsilon);
+    he1 = dmax(stateT[qT + 3 * nc], epsilon);
+  } else {
+    const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+    nd = ndens[q];
+    h0 = dmax(xh_av[q], epsilon);
+    he0 = dmax(xhe_av[q], epsilon);
+    he1 = dmax(xhe_av[q + nc], epsilon);
+  }
+  ShellCorners c4;
+  shell_short_characteristic(G, face, S.i0, S.j0, S.k0, di, dj, dk, c4);
+  double cin_HI = interp_column_fast(c4.s, cs[col_out((size_t)c4.p[0], 0, cz)], cs[col_out((size_t)c4.p[1], 0, cz)],
+                                     cs[col_out((size_t)c4.p[2], 0, cz)], cs[col_out((size_t)c4.p[3], 0, cz)], sigma_HI_at_ion_freq);
+  const double cin_HeI = interp_column_fast(c4.s, cs[col_out((size_t)c4.p[0], 1, cz)], cs[col_out((size_t)c4.p[1], 1, cz)],
+                                            cs[col_out((size_t)c4.p[2], 1, cz)], cs[col_out((size_t)c4.p[3], 1, cz)], sigma_HeI_at_ion_freq);
+  const double cin_HeII = interp_column_fast(c4.s, cs[col_out((size_t)c4.p[0], 2, cz)], cs[col_out((size_t)c4.p[1], 2, cz)],
+                                             cs[col_out((size_t)c4.p[2], 2, cz)], cs[col_out((size_t)c4.p[3], 2, cz)], sigma_HeII_at_ion_freq);
+  const double path = c4.path * sc.dr1;
+  if (sc.use_lls) {
+    // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180)
+    const double coldensh_LLS =
+        lls_grid ? (double)lls_grid[(size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k)] : sc.coldensh_lls;
+    cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
   }
   const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
   const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
@@ -1182,6 +1207,7 @@ struct c2r_ctx {
   int *d_block_base = nullptr;     // device copy of block_base
   int blocks_total = 0;            // blocks of all shells 0..smax
   std::vector<int> block_base;     // first block of shell s in a partial-sum row
+  std::vector<ShellGeom> shell_geom; // per-shell constants of k_sweep_shell_fast
   double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
   double *d_stateT = nullptr;      // 4 ncell: (j,i,k)-ordered ndens, xh_av(0), xhe_av(0), xhe_av(1)
   double *d_rc_last = nullptr;     // 12: coefficients left by the last cell of the chemistry pass
@@ -1428,6 +1454,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   for (int s = 0; s <= c->g.smax; s++)
     c->block_base[s + 1] = c->block_base[s] + (int)((shell_count(s) + BLOCK - 1) / BLOCK);
   c->blocks_total = c->block_base[c->g.smax + 1];
+  for (int s = 0; s <= c->g.smax; s++) c->shell_geom.push_back(shell_geometry(s));
   CR(hipMalloc(&c->d_block_base, sizeof(int) * c->block_base.size()));
   CR(hipMemcpy(c->d_block_base, c->block_base.data(), sizeof(int) * c->block_base.size(), hipMemcpyHostToDevice));
   c->ntiles = (size_t)((mesh[0] + 7) / 8) * ((mesh[1] + 7) / 8) * ((mesh[2] + 3) / 4);
@@ -2463,9 +2490,16 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
         const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
-        hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + act_off,
-                           s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, transposed_seen ? c->d_stateT : nullptr,
-                           c->lls_on_grid ? c->d_lls : nullptr);
+        // C2R_SWEEP_GENERIC=1 (diagnostic): every shell through the general kernel
+        static const bool generic_sweep = getenv("C2R_SWEEP_GENERIC") && atoi(getenv("C2R_SWEEP_GENERIC")) > 0;
+        if (s >= 2 && !generic_sweep)
+          hipLaunchKernelGGL(k_sweep_shell_fast, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set],
+                             c->d_list[set] + act_off, c->shell_geom[(size_t)s], box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av,
+                             transposed_seen ? c->d_stateT : nullptr, c->lls_on_grid ? c->d_lls : nullptr);
+        else
+          hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + act_off,
+                             s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, transposed_seen ? c->d_stateT : nullptr,
+                             c->lls_on_grid ? c->d_lls : nullptr);
         c->tm.sweep_launches++;
       }
       HIPCHK(c, hipGetLastError());

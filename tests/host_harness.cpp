@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../c2-ray3dm1d_helium_amd/csrc/c2ray_device.hpp"
+#include "../c2-ray3dm1d_helium_amd/csrc/c2ray_shell.hpp"
 
 using namespace c2r;
 
@@ -204,5 +205,48 @@ int hh_constants(double *out, int n) {
   const int m = (int)(sizeof c / sizeof c[0]);
   for (int i = 0; i < m && i < n; i++) out[i] = c[i];
   return m;
+}
+
+// The per-shell geometry of k_sweep_shell_fast (csrc/c2ray_shell.hpp) against the general functions it replaces, for
+// every cell of the shells 2..smax around a source at (i0,j0,k0): the thread -> cell map with its magic divisions,
+// the bilinear weights and the path length (bit for bit), and the corner positions -- equal to the general inverse
+// map wherever the corner's weight is not exactly zero, and inside shell s-1 where it is.  Returns the number of
+// mismatches (first one described in what[0..7]: shell, t, kind, corner).
+int hh_check_shell_geometry(int smax, int i0, int j0, int k0, int *what) {
+  int bad = 0;
+  auto note = [&](int s, int t, int kind, int c) {
+    if (bad++ == 0 && what) { what[0] = s; what[1] = t; what[2] = kind; what[3] = c; }
+  };
+  for (int s = 2; s <= smax; s++) {
+    const ShellGeom G = shell_geometry(s);
+    if (G.alam * (double)s != (double)s - 0.5) note(s, -1, 0, 0); // the weight-zero argument rests on this
+    const int cnt = (int)shell_count(s);
+    for (int t = 0; t < cnt; t++) {
+      int di, dj, dk, fi, fj, fk;
+      shell_decode(s, t, di, dj, dk);
+      const int face = shell_decode_fast(G, t, fi, fj, fk);
+      if (fi != di || fj != dj || fk != dk) { note(s, t, 1, 0); continue; }
+      const int ia = di < 0 ? -di : di, ja = dj < 0 ? -dj : dj, ka = dk < 0 ? -dk : dk;
+      const int want_face = ka == s ? 0 : (ja == s ? 1 : 2);
+      if (face != want_face) { note(s, t, 2, 0); continue; }
+      if ((long long)shell_position(di, dj, dk) != G.off + t) note(s, t, 3, 0);
+      ShortChar ref;
+      short_characteristic(i0, j0, k0, di, dj, dk, ref);
+      ShellCorners got;
+      shell_short_characteristic(G, face, i0, j0, k0, di, dj, dk, got);
+      if (ref.diag != 1.0) note(s, t, 4, 0);
+      if (std::memcmp(&ref.path, &got.path, sizeof(double)) != 0) note(s, t, 5, 0);
+      for (int c = 0; c < 4; c++) {
+        if (std::memcmp(&ref.s[c], &got.s[c], sizeof(double)) != 0) note(s, t, 6, c);
+        const long long pref = (long long)shell_position(ref.ci[c], ref.cj[c], ref.ck[c]);
+        if (ref.s[c] != 0.0) {
+          if (pref != got.p[c]) note(s, t, 7, c);
+        } else if (got.p[c] < G.offp || got.p[c] >= G.off) {
+          note(s, t, 8, c);
+        }
+      }
+    }
+  }
+  return bad;
 }
 }

@@ -127,3 +127,22 @@ def test_multi_sed_photoion_equals_oracle(hh, orc, pkg, gold):
             assert np.array_equal(out, r[[0, 1, 2, 18, 20]]), (n, heat)
         hh.hh_photo_out_multi.restype = C.c_double
         assert hh.hh_photo_out_multi(_p(cin), _p(nf)) == r[20]
+
+
+@pytest.mark.parametrize("src", [(1, 1, 1), (7, 3, 12), (128, 128, 128), (255, 1, 77), (512, 300, 2)])
+def test_per_shell_geometry_of_the_fast_sweep_equals_the_general_functions(harness, src):
+    """csrc/c2ray_shell.hpp (what k_sweep_shell_fast computes per cell from per-shell constants) against
+    short_characteristic + shell_position + shell_decode, every cell of shells 2..40 and a few large shells: decode,
+    weights and path bit for bit; corner positions equal wherever the weight is not exactly zero."""
+    what = (C.c_int * 8)()
+    assert harness.hh_check_shell_geometry(40, *src, what) == 0, list(what)
+
+
+def test_per_shell_constants_hold_for_every_shell_of_the_largest_mesh(harness):
+    """(s - 1/2) / s * s == s - 1/2 in double (the corners on the edges of a face have weight exactly 0), and the magic
+    divisions of the thread -> cell map, up to the largest shell a mesh can have (checked inside the harness for the
+    shells it visits; here the arithmetic claim for all of them)."""
+    s = np.arange(1, 4097, dtype=np.float64)
+    assert np.array_equal(((s - 0.5) / s) * s, s - 0.5)
+    # a large shell end to end (24 s^2 + 2 cells): s = 300 alone, by giving smax = 300 to a harness that starts at 2 would
+    # take minutes; shells 296..300 are reached through the GPU tests at 512^3 and 600-cell meshes
