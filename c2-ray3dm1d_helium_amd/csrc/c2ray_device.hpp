@@ -489,10 +489,12 @@ C2R_HD TauPos tau_table_position(double tau, const double *logtab = C2R_LOGTAB_D
 // Two optical depths at once (the two faces of a cell): both table-path evaluations of the log run as one
 // straight line -- their loads and dependent fma chains overlap --, and the polynomial path of __log_fma
 // (arguments near 1: one in ten, spatially coherent) is entered only when some lane of the wave needs it.
+// `logtab4`, when given, is the table with the power of two folded in (gm::LogEntry; k_rates keeps it in LDS).
 C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab, TauPos &pa, TauPos &pb,
-                                const gm::LogPins *pins = nullptr) {
+                                const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
   const gm::Log10Arg a = gm::log10_split(dmax_const(tau_a, 1.0e-20)), b = gm::log10_split(dmax_const(tau_b, 1.0e-20));
-  double lga = gm::log_table_path(a, logtab, pins), lgb = gm::log_table_path(b, logtab, pins);
+  double lga = logtab4 ? gm::log_table_path4(a, logtab4, pins) : gm::log_table_path(a, logtab, pins);
+  double lgb = logtab4 ? gm::log_table_path4(b, logtab4, pins) : gm::log_table_path(b, logtab, pins);
   const bool na = gm::log10_near1(a), nb = gm::log10_near1(b);
   C2R_COUNT_LANES(12, na || nb);
   C2R_COUNT_LANES(15, na && nb);
@@ -508,7 +510,8 @@ C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab
 C2R_HD TauPos tau_table_position(double tau, const double * = nullptr) {
   return table_position_of_log(C2R_MATH_LOG10N(dmax(1.0e-20, tau)));
 }
-C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *, TauPos &pa, TauPos &pb) {
+C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *, TauPos &pa, TauPos &pb, const void * = nullptr,
+                                const void * = nullptr) {
   pa = tau_table_position(tau_a);
   pb = tau_table_position(tau_b);
 }
@@ -569,6 +572,7 @@ struct CellSrc {
   Recip rvol;      // the shell volume vol_ph as divisor
   bool recip_safe; // the sums of scale_int2/3 lie where recip_nr is exact (see there)
   const gm::LogPins *pins; // see gm::LogPins; may be null
+  const gm::LogEntry *logtab4; // see tau_table_positions; may be null
 };
 
 // RN(1/x) for the denominators of scale_int2 / scale_int3: the instruction sequence the compiler emits for 1.0/x
@@ -663,7 +667,7 @@ C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const doub
   // both positions always: an optically thin band (no use for pout) is rare, and one straight line for the
   // two logs is worth more than skipping one of them now and then
   TauPos pin, pout;
-  tau_table_positions(tau_in, tau_out, logtab, pin, pout, c.pins);
+  tau_table_positions(tau_in, tau_out, logtab, pin, pout, c.pins, c.logtab4);
 
   // species split of this band (scale_int2 / scale_int3)
   double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
@@ -818,7 +822,7 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
                       const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
                       double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
                       double NFlux, const Ricotti &ric, SedAcc &out, const double *logtab, const double *tau_zero,
-                      const gm::LogPins *pins = nullptr) {
+                      const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
   out.photo_HI = out.photo_HeI = out.photo_HeII = 0.0;
   out.photo_out = 0.0;
   out.f_heat = out.f_ion_HI = out.f_ion_HeI = 0.0;
@@ -832,6 +836,7 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
   c.NFlux = NFlux;
   c.rvol = make_recip(vol);
   c.pins = pins;
+  c.logtab4 = logtab4;
   c.recip_safe = column_in_recip_range(c.cell_HI) && column_in_recip_range(c.cell_HeI) && column_in_recip_range(c.cell_HeII);
   SedSums o = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const int e0 = bhi < NB1 ? bhi : NB1, e1 = bhi < NB1 + NB2 ? bhi : NB1 + NB2;
@@ -872,10 +877,10 @@ C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const 
                            const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
                            double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
                            double NFlux, const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT,
-                           const gm::LogPins *pins = nullptr) {
+                           const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
   SedAcc a;
   sed_rates<HEAT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
-                  cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab, bd.tau_zero[0], pins);
+                  cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab, bd.tau_zero[0], pins, logtab4);
   o.photo_HI = a.photo_HI;
   o.photo_HeI = a.photo_HeI;
   o.photo_HeII = a.photo_HeII;
@@ -904,7 +909,7 @@ template <bool HEAT>
 C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                                  double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
                                  const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT,
-                                 const gm::LogPins *pins = nullptr) {
+                                 const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
@@ -917,7 +922,7 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
     act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
     if (act[s])
       sed_rates<HEAT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
-                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s], pins);
+                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s], pins, logtab4);
   }
   // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
   for (int s = 0; s < NSED; s++) {

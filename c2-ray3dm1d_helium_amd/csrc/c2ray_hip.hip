@@ -128,19 +128,49 @@ __host__ __device__ inline size_t col_out(size_t p, int k, size_t cz) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// (i,j,k) -> (j,i,k) copies of the four state grids the sweep reads, so that the cells of a
-// shell's i-faces (fixed i, consecutive j) are consecutive in memory too.  32x32 tiles through LDS.
-// src/dst: 4 arrays given by pointer; layout of dst: index = j + n2*(i + n1*k).
-struct Ptr4 {
-  const double *src[4];
-  double *dst[4];
-};
+// What the sweep needs of a cell's state, once per pass instead of once per cell.source: the three products
+// neufrac * ndens of coldens (doric.f90:358-372: neufrac*ndens*path*abundance is evaluated from the left, so the
+// first product does not depend on the source) for HI, HeI, HeII with the fractions clamped at epsilon
+// (evolve_point.F90:132-136) -- 24 bytes per cell.source instead of 32 --, in mesh order (`packed`, index
+// i + n1*(j + n2*k)) and, for the i-faces of a shell (fixed i, consecutive j), in (j,i,k) order (`packedT`, index
+// j + n2*(i + n1*k)); three arrays of ncell each.  32x32 tiles of a k-plane through LDS.
 __global__ void __launch_bounds__(BLOCK)
-k_transpose_ij(Grid g, Ptr4 P) {
+k_pack_state(Grid g, const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
+             double *__restrict__ packed, double *__restrict__ packedT) {
+  __shared__ double tile[3][32][33];
+  const size_t nc = g.ncell;
+  const int k = blockIdx.z;
+  const size_t plane = (size_t)k * g.n1 * g.n2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + tx, j = j0 + r;
+    if (i < g.n1 && j < g.n2) {
+      const size_t q = plane + (size_t)i + (size_t)g.n1 * j;
+      const double nd = ndens[q];
+      const double u0 = dmax(xh_av[q], epsilon) * nd, u1 = dmax(xhe_av[q], epsilon) * nd, u2 = dmax(xhe_av[q + nc], epsilon) * nd;
+      packed[q] = u0; packed[q + nc] = u1; packed[q + 2 * nc] = u2;
+      tile[0][r][tx] = u0; tile[1][r][tx] = u1; tile[2][r][tx] = u2;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = j0 + tx, i = i0 + r;
+    if (i < g.n1 && j < g.n2) {
+      const size_t qT = plane + (size_t)j + (size_t)g.n2 * i;
+      packedT[qT] = tile[0][tx][r]; packedT[qT + nc] = tile[1][tx][r]; packedT[qT + 2 * nc] = tile[2][tx][r];
+    }
+  }
+}
+
+// packed -> packedT alone, when the global pass has left `packed` up to date (k_chemistry writes it with the
+// fractions it stores): 24 bytes read and written per cell instead of 32 and 48
+__global__ void __launch_bounds__(BLOCK)
+k_transpose_packed(Grid g, const double *__restrict__ packed, double *__restrict__ packedT) {
   __shared__ double tile[32][33];
   const int a = blockIdx.z / g.n3, k = blockIdx.z % g.n3;
-  const double *src = P.src[a] + (size_t)k * g.n1 * g.n2;
-  double *dst = P.dst[a] + (size_t)k * g.n1 * g.n2;
+  const double *src = packed + (size_t)a * g.ncell + (size_t)k * g.n1 * g.n2;
+  double *dst = packedT + (size_t)a * g.ncell + (size_t)k * g.n1 * g.n2;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
   const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
   for (int r = ty; r < 32; r += 8) {
@@ -340,52 +370,58 @@ k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ lis
 #ifndef C2R_SWEEP_WAVES
 #define C2R_SWEEP_WAVES 1
 #endif
-__global__ void __launch_bounds__(BLOCK, C2R_SWEEP_WAVES)
-k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ active, int shell, Box box, StepScalars sc,
-              const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
-              const double *__restrict__ stateT, const float *__restrict__ lls_grid) {
-  const SrcDev &S = src[active[blockIdx.y]];
-  const long long cnt = shell_count(shell);
-  // Which 256 cells of the shell this block takes.  Blocks are dealt round-robin over the 8 XCDs, each with its
-  // own L2: with block b on cells [256 b, 256 b + 256) the two rows of the previous shell that a row of cells
-  // reads are fetched by two or three XCDs.  Instead the blocks of one XCD (equal b mod 8) take one contiguous
-  // eighth of the shell, so that a previous-shell line is fetched by one L2 (the host rounds launches of 64
-  // blocks or more up to a multiple of 8; the surplus blocks leave at once).
-  const int nblk_shell = (int)((cnt + BLOCK - 1) / BLOCK);
-  int vb = (int)blockIdx.x;
-  if ((gridDim.x & 7u) == 0) {
-    const int chunk = (int)gridDim.x >> 3;
-    vb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+// what every cell of a sweep launch is given
+struct SweepArgs {
+  Grid g;
+  Box box;
+  StepScalars sc;
+  const double *ndens, *xh_av, *xhe_av;
+  const double *packed, *packedT; // neufrac * ndens of the three species in mesh and in (j,i,k) order (k_pack_state,
+                                  // k_chemistry, k_transpose_packed); null while they are being made
+  const float *lls_grid;
+};
+
+// neufrac * ndens of the three species for the cell at mesh position (i,j,k), 0-based (k_pack_state), or from the
+// grids while the packed copies of this pass are still being made (the inner shells); iface: the cell lies on an
+// i-face of its shell, where consecutive lanes have consecutive j -> the (j,i,k)-ordered copy
+__device__ __forceinline__ void sweep_cell_state(const SweepArgs &A, int i, int j, int k, bool iface, double &u_HI, double &u_HeI,
+                                                 double &u_HeII) {
+  const Grid &g = A.g;
+  const size_t nc = g.ncell;
+  if (A.packed) {
+    const bool tr = iface && A.packedT; // (the inner shells run before the (j,i,k)-ordered copy exists: strided reads)
+    const double *P = tr ? A.packedT : A.packed;
+    const size_t q = tr ? (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k)
+                        : (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+    u_HI = P[q];
+    u_HeI = P[q + nc];
+    u_HeII = P[q + 2 * nc];
+  } else {
+    const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+    const double nd = A.ndens[q];
+    u_HI = dmax(A.xh_av[q], epsilon) * nd;
+    u_HeI = dmax(A.xhe_av[q], epsilon) * nd;
+    u_HeII = dmax(A.xhe_av[q + nc], epsilon) * nd;
   }
-  if (vb >= nblk_shell) return;
-  const long long t = (long long)vb * BLOCK + threadIdx.x;
-  if (t >= cnt) return;
+}
+
+// evolve0D's column part (files_for_3D/evolve_point.F90:114-168, :237-244) for cell t of shell `shell` around source
+// S, any shell: cinterp through the general short_characteristic / shell_position
+__device__ __forceinline__ void sweep_cell(const SweepArgs &A, const SrcDev &S, int shell, int t) {
+  const Grid &g = A.g;
+  const StepScalars &sc = A.sc;
   int di, dj, dk;
-  shell_decode(shell, (int)t, di, dj, dk);
-  const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
-                      dk <= box.hi[2];
+  shell_decode(shell, t, di, dj, dk);
+  const bool inside = di >= A.box.lo[0] && di <= A.box.hi[0] && dj >= A.box.lo[1] && dj <= A.box.hi[1] && dk >= A.box.lo[2] &&
+                      dk <= A.box.hi[2];
   if (!inside) return;
-  const size_t nc = g.ncell, cz = S.cz;
+  const size_t cz = S.cz;
   const size_t p = (size_t)shell_offset(shell) + (size_t)t;
   global_double *cs = (global_double *)S.cols;
-  double nd, h0, he0, he1;
+  const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
   const int w_ = 2 * shell + 1;
-  if (stateT && shell > 0 && t >= (long long)2 * w_ * w_ + (long long)2 * (w_ - 2) * w_) {
-    // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies (not given for the inner
-    // shells, whose faces are small and which run while the copies are still being made)
-    const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
-    const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
-    nd = stateT[qT];
-    h0 = dmax(stateT[qT + nc], epsilon);
-    he0 = dmax(stateT[qT + 2 * nc], epsilon);
-    he1 = dmax(stateT[qT + 3 * nc], epsilon);
-  } else {
-    const size_t q = cell_index(g, S.i0, S.j0, S.k0, di, dj, dk);
-    nd = ndens[q];
-    h0 = dmax(xh_av[q], epsilon);
-    he0 = dmax(xhe_av[q], epsilon);
-    he1 = dmax(xhe_av[q + nc], epsilon);
-  }
+  double u_HI, u_HeI, u_HeII;
+  sweep_cell_state(A, i, j, k, shell > 0 && t >= 2 * w_ * w_ + 2 * (w_ - 2) * w_, u_HI, u_HeI, u_HeII);
   double cin_HI, cin_HeI, cin_HeII, path;
   if (shell == 0) {
     cin_HI = cin_HeI = cin_HeII = 0.0;
@@ -407,13 +443,14 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
       // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180); the per-cell
       // grid is LLS_point of type_of_LLS = 2 (REAL(4), mat_ini_cubep3m.F90:859-870)
       const double coldensh_LLS =
-          lls_grid ? (double)lls_grid[cell_index(g, S.i0, S.j0, S.k0, di, dj, dk)] : sc.coldensh_lls;
+          A.lls_grid ? (double)A.lls_grid[(size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k)] : sc.coldensh_lls;
       cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
     }
   }
-  const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
-  const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
-  const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
+  // coldens (doric.f90:358-372): neufrac * ndens * path * abundance, from the left
+  const double cout_HI = cin_HI + u_HI * path * (1.0 - abu_he);
+  const double cout_HeI = cin_HeI + u_HeI * path * abu_he;
+  const double cout_HeII = cin_HeII + u_HeII * path * abu_he;
   cs[col_in(p, 0, cz)] = cin_HI;
   cs[col_in(p, 1, cz)] = cin_HeI;
   cs[col_in(p, 2, cz)] = cin_HeII;
@@ -427,47 +464,21 @@ k_sweep_shell(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ ac
 // constant, the path's division by s^2 as three fma, the 12 reciprocals of weightf without the division's operand
 // scaling, and the corners' positions from the face formulas of shell s-1 instead of four general inverse maps
 // (corners of weight exactly 0 on the edges of a face are read from the nearest cell of shell s-1).  Bit for bit
-// the columns of k_sweep_shell (tests: C2R_SWEEP_GENERIC=1 runs that one for every shell).
-__global__ void __launch_bounds__(BLOCK, C2R_SWEEP_WAVES)
-k_sweep_shell_fast(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ active, ShellGeom G, Box box, StepScalars sc,
-                   const double *__restrict__ ndens, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
-                   const double *__restrict__ stateT, const float *__restrict__ lls_grid) {
-  const SrcDev &S = src[active[blockIdx.y]];
-  const int cnt = 24 * G.s * G.s + 2;
-  // blocks of one XCD (equal blockIdx.x mod 8) take one contiguous eighth of the shell (see k_sweep_shell)
-  const int nblk_shell = (cnt + BLOCK - 1) / BLOCK;
-  int vb = (int)blockIdx.x;
-  if ((gridDim.x & 7u) == 0) {
-    const int chunk = (int)gridDim.x >> 3;
-    vb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
-  }
-  if (vb >= nblk_shell) return;
-  const int t = vb * BLOCK + (int)threadIdx.x;
-  if (t >= cnt) return;
+// the columns of sweep_cell (tests: C2R_SWEEP_GENERIC=1 runs that one for every shell).
+__device__ __forceinline__ void sweep_cell_fast(const SweepArgs &A, const SrcDev &S, const ShellGeom &G, int t) {
+  const Grid &g = A.g;
+  const StepScalars &sc = A.sc;
   int di, dj, dk;
   const int face = shell_decode_fast(G, t, di, dj, dk);
-  const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
-                      dk <= box.hi[2];
+  const bool inside = di >= A.box.lo[0] && di <= A.box.hi[0] && dj >= A.box.lo[1] && dj <= A.box.hi[1] && dk >= A.box.lo[2] &&
+                      dk <= A.box.hi[2];
   if (!inside) return;
-  const size_t nc = g.ncell, cz = S.cz;
+  const size_t cz = S.cz;
   const size_t p = (size_t)G.off + (size_t)t;
   global_double *cs = (global_double *)S.cols;
   const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
-  double nd, h0, he0, he1;
-  if (stateT && face == 2) {
-    // i-face: consecutive lanes have consecutive j -> read the (j,i,k)-ordered copies
-    const size_t qT = (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k);
-    nd = stateT[qT];
-    h0 = dmax(stateT[qT + nc], epsilon);
-    he0 = dmax(stateT[qT + 2 * nc], epsilon);
-    he1 = dmax(stateT[qT + 3 * nc], epsilon);
-  } else {
-    const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
-    nd = ndens[q];
-    h0 = dmax(xh_av[q], epsilon);
-    he0 = dmax(xhe_av[q], epsilon);
-    he1 = dmax(xhe_av[q + nc], epsilon);
-  }
+  double u_HI, u_HeI, u_HeII;
+  sweep_cell_state(A, i, j, k, face == 2, u_HI, u_HeI, u_HeII);
   ShellCorners c4;
   shell_short_characteristic(G, face, S.i0, S.j0, S.k0, di, dj, dk, c4);
   double cin_HI = interp_column_fast(c4.s, cs[col_out((size_t)c4.p[0], 0, cz)], cs[col_out((size_t)c4.p[1], 0, cz)],
@@ -480,18 +491,48 @@ k_sweep_shell_fast(Grid g, const SrcDev *__restrict__ src, const int *__restrict
   if (sc.use_lls) {
     // Lyman-limit-system fog on the incoming HI column (evolve_point.F90:177-180)
     const double coldensh_LLS =
-        lls_grid ? (double)lls_grid[(size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k)] : sc.coldensh_lls;
+        A.lls_grid ? (double)A.lls_grid[(size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k)] : sc.coldensh_lls;
     cin_HI = cin_HI + coldensh_LLS * path / sc.dr1;
   }
-  const double cout_HI = cin_HI + coldens(path, h0, nd, (1.0 - abu_he));
-  const double cout_HeI = cin_HeI + coldens(path, he0, nd, abu_he);
-  const double cout_HeII = cin_HeII + coldens(path, he1, nd, abu_he);
+  // coldens (doric.f90:358-372): neufrac * ndens * path * abundance, from the left
+  const double cout_HI = cin_HI + u_HI * path * (1.0 - abu_he);
+  const double cout_HeI = cin_HeI + u_HeI * path * abu_he;
+  const double cout_HeII = cin_HeII + u_HeII * path * abu_he;
   cs[col_in(p, 0, cz)] = cin_HI;
   cs[col_in(p, 1, cz)] = cin_HeI;
   cs[col_in(p, 2, cz)] = cin_HeII;
   cs[col_out(p, 0, cz)] = cout_HI;
   cs[col_out(p, 1, cz)] = cout_HeI;
   cs[col_out(p, 2, cz)] = cout_HeII;
+}
+
+// Which 256 cells of a shell of `cnt` cells a block takes (-1: none).  Blocks are dealt round-robin over the 8 XCDs,
+// each with its own L2: with block b on cells [256 b, 256 b + 256) the two rows of the previous shell that a row of
+// cells reads are fetched by two or three XCDs.  Instead the blocks of one XCD (equal b mod 8) take one contiguous
+// eighth of the shell, so that a previous-shell line is fetched by one L2 (the host rounds launches of 64 blocks or
+// more up to a multiple of 8; the surplus blocks leave at once).
+__device__ __forceinline__ int sweep_block_cell(int cnt) {
+  const int nblk_shell = (cnt + BLOCK - 1) / BLOCK;
+  int vb = (int)blockIdx.x;
+  if ((gridDim.x & 7u) == 0) {
+    const int chunk = (int)gridDim.x >> 3;
+    vb = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+  }
+  if (vb >= nblk_shell) return -1;
+  const int t = vb * BLOCK + (int)threadIdx.x;
+  return t < cnt ? t : -1;
+}
+
+__global__ void __launch_bounds__(BLOCK, C2R_SWEEP_WAVES)
+k_sweep_shell(SweepArgs A, const SrcDev *__restrict__ src, const int *__restrict__ active, int shell) {
+  const int t = sweep_block_cell((int)shell_count(shell));
+  if (t >= 0) sweep_cell(A, src[active[blockIdx.y]], shell, t);
+}
+
+__global__ void __launch_bounds__(BLOCK, C2R_SWEEP_WAVES)
+k_sweep_shell_fast(SweepArgs A, const SrcDev *__restrict__ src, const int *__restrict__ active, ShellGeom G) {
+  const int t = sweep_block_cell(24 * G.s * G.s + 2);
+  if (t >= 0) sweep_cell_fast(A, src[active[blockIdx.y]], G, t);
 }
 
 // photon_loss_src_thread(tn) += ... (evolve_point.F90:312): sum the block partials of all shells of
@@ -645,6 +686,14 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   // queue behind the photo-table gathers in the vector memory path
   __shared__ double s_logtab[256];
   s_logtab[threadIdx.x] = gm::log_table()[threadIdx.x];
+  // the same with the log's power of two folded in (gm::LogEntry, 8 KB): what the band loop reads
+#ifndef C2R_NO_LOGTAB4
+  __shared__ gm::LogEntry s_logtab4_[256];
+  s_logtab4_[threadIdx.x] = gm::make_log_entry((int)threadIdx.x);
+  const gm::LogEntry *s_logtab4 = s_logtab4_;
+#else
+  const gm::LogEntry *s_logtab4 = nullptr;
+#endif
   __syncthreads();
   // two polynomial constants of the log held in vector registers for the whole kernel (gm::LogPins): -0.25 ms per
   // launch in the isothermal kernel; the heating kernels, which have no registers to spare, lose 2.7 ms with them
@@ -733,10 +782,10 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
         PhotoOut o;
         if (MULTI) {
           const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-          photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab, pins);
+          photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab, pins, s_logtab4);
         } else {
           photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
-                               cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab, pins);
+                               cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab, pins, s_logtab4);
         }
         a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
         a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);
@@ -790,7 +839,8 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
             const float *__restrict__ clumping_grid, size_t q_first, size_t q_end, const int *__restrict__ list,
-            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist, int part) {
+            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist, int part,
+            double *__restrict__ packed) {
   // Cells are taken from the range [q_first, q_end) or, when `list` is given, from list[q_first .. q_end).
   // Heating runs (hist != null): budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps --
   // nothing of it is stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds
@@ -913,6 +963,10 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
     xh_av[q] = ion.h_av[0];     xh_av[q + nc] = ion.h_av[1];
     xhe_int[q] = ion.he[0];     xhe_int[q + nc] = ion.he[1];     xhe_int[q + 2 * nc] = ion.he[2];
     xhe_av[q] = ion.he_av[0];   xhe_av[q + nc] = ion.he_av[1];   xhe_av[q + 2 * nc] = ion.he_av[2];
+    // what the next pass's column sweep reads of this cell (k_pack_state): neufrac * ndens, fractions clamped at epsilon
+    packed[q] = dmax(ion.h_av[0], epsilon) * ndens_p;
+    packed[q + nc] = dmax(ion.he_av[0], epsilon) * ndens_p;
+    packed[q + 2 * nc] = dmax(ion.he_av[1], epsilon) * ndens_p;
     } // not dropped
   }
   if (HEAT && hist) { // one atomic per wave and distinct bucket
@@ -1209,7 +1263,9 @@ struct c2r_ctx {
   std::vector<int> block_base;     // first block of shell s in a partial-sum row
   std::vector<ShellGeom> shell_geom; // per-shell constants of k_sweep_shell_fast
   double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
-  double *d_stateT = nullptr;      // 4 ncell: (j,i,k)-ordered ndens, xh_av(0), xhe_av(0), xhe_av(1)
+  double *d_stateT = nullptr;      // 6 ncell: k_pack_state's products in mesh order (3 ncell), then in (j,i,k) order
+  bool packed_valid = false;       // the mesh-ordered half matches xh_av / xhe_av (a complete global pass wrote it)
+  size_t chem_cells = 0;           // cells the open global pass has been asked to do so far
   double *d_rc_last = nullptr;     // 12: coefficients left by the last cell of the chemistry pass
   double *d_stat = nullptr;        // STAT_BLOCKS*5 partials + 8 results
   double *h_stat = nullptr;        // pinned, 8
@@ -1439,7 +1495,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMalloc(&c->d_xh_int, sizeof(double) * 2 * nc));
   CR(hipMalloc(&c->d_xhe_int, sizeof(double) * 3 * nc));
   CR(hipMalloc(&c->d_temp, sizeof(float) * 3 * nc));
-  CR(hipMalloc(&c->d_stateT, sizeof(double) * 4 * nc));
+  CR(hipMalloc(&c->d_stateT, sizeof(double) * 6 * nc));
   CR(hipMalloc(&c->d_rc_last, sizeof(double) * 12));
   CR(hipMemset(c->d_rc_last, 0, sizeof(double) * 12));
   CR(hipMalloc(&c->d_stat, sizeof(double) * (STAT_BLOCKS * 5 + 8)));
@@ -1693,6 +1749,7 @@ static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], dou
   c->zred = zred; c->H0 = H0; c->Omega0 = Omega0;
   c->isothermal = isothermal ? 1 : 0;
   c->have_step = true;
+  c->packed_valid = false; // ndens may have changed
   return 0;
 }
 
@@ -1956,6 +2013,7 @@ static StepScalars scalars(c2r_ctx *c) {
 static int begin_step_one(c2r_ctx *c) {
   if (!c) return 1;
   if (!c->have_state) return fail(c, "c2r_begin_step: c2r_upload_state has not been called");
+  c->packed_valid = false; // xh_av, xhe_av are overwritten below
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
   HIPCHK(c, hipMemcpyAsync(c->d_xh_av, c->d_xh, sizeof(double) * 2 * nc, hipMemcpyDeviceToDevice, c->stream));
@@ -2225,17 +2283,21 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
 
   {
-    // (j,i,k)-ordered copies of the state the sweep reads (xh_av, xhe_av change every iteration): made on the third
-    // stream while the inner shells, which do without them, are already on their way
-    Ptr4 P;
-    P.src[0] = c->d_ndens; P.src[1] = c->d_xh_av; P.src[2] = c->d_xhe_av; P.src[3] = c->d_xhe_av + nc;
-    for (int a = 0; a < 4; a++) P.dst[a] = c->d_stateT + (size_t)a * nc;
+    // the products neufrac * ndens the sweep reads (k_pack_state; xh_av, xhe_av change every iteration), in mesh
+    // order and in (j,i,k) order: made on the third stream while the inner shells, which do without them, are
+    // already on their way
     HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_sweep_done[0], 0));
-    hipLaunchKernelGGL(k_transpose_ij, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 4 * g.n3), dim3(BLOCK), 0, c->stream3, g, P);
+    if (c->packed_valid)
+      hipLaunchKernelGGL(k_transpose_packed, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 3 * g.n3), dim3(BLOCK), 0, c->stream3, g,
+                         c->d_stateT, c->d_stateT + 3 * nc);
+    else
+      hipLaunchKernelGGL(k_pack_state, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, g.n3), dim3(BLOCK), 0, c->stream3, g, c->d_ndens, c->d_xh_av,
+                         c->d_xhe_av, c->d_stateT, c->d_stateT + 3 * nc);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_transposed, c->stream3));
   }
   bool transposed_seen = false; // the sweep stream has waited for ev_transposed
+  const bool packed_early = c->packed_valid; // the mesh-ordered products need not wait for anything
   // slabs: tile layers (4 planes each) [slab_layer[s], slab_layer[s+1])
   const int nt3_all = (g.n3 + 3) / 4;
   const int ns_eff = nslab > 0 ? std::min(nslab, nt3_all) : 0;
@@ -2481,25 +2543,29 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       }
       cur_off = act_off;
       cur_nact = nact;
+      // C2R_SWEEP_GENERIC=1 (diagnostic): every shell through the general per-cell code, one launch per shell
+      static const bool generic_sweep = getenv("C2R_SWEEP_GENERIC") && atoi(getenv("C2R_SWEEP_GENERIC")) > 0;
+      SweepArgs SA;
+      SA.g = g; SA.box = box; SA.sc = sc;
+      SA.ndens = c->d_ndens; SA.xh_av = c->d_xh_av; SA.xhe_av = c->d_xhe_av;
+      SA.lls_grid = c->lls_on_grid ? c->d_lls : nullptr;
       for (int s = s_lo; s <= s_hi; s++) {
         // (a large batch waits at once: its many small faces would pay more for strided reads than the wait costs)
         if ((s >= TRANSPOSED_FROM_SHELL || nb > 16) && !transposed_seen) {
           HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_transposed, 0));
           transposed_seen = true;
         }
+        SA.packed = SA.packedT = nullptr;
+        if (transposed_seen || packed_early) SA.packed = c->d_stateT;
+        if (transposed_seen) SA.packedT = c->d_stateT + 3 * nc;
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
         const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
-        // C2R_SWEEP_GENERIC=1 (diagnostic): every shell through the general kernel
-        static const bool generic_sweep = getenv("C2R_SWEEP_GENERIC") && atoi(getenv("C2R_SWEEP_GENERIC")) > 0;
         if (s >= 2 && !generic_sweep)
-          hipLaunchKernelGGL(k_sweep_shell_fast, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set],
-                             c->d_list[set] + act_off, c->shell_geom[(size_t)s], box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av,
-                             transposed_seen ? c->d_stateT : nullptr, c->lls_on_grid ? c->d_lls : nullptr);
+          hipLaunchKernelGGL(k_sweep_shell_fast, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, SA, c->d_src[set],
+                             c->d_list[set] + act_off, c->shell_geom[(size_t)s]);
         else
-          hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, g, c->d_src[set], c->d_list[set] + act_off,
-                             s, box, sc, c->d_ndens, c->d_xh_av, c->d_xhe_av, transposed_seen ? c->d_stateT : nullptr,
-                             c->lls_on_grid ? c->d_lls : nullptr);
+          hipLaunchKernelGGL(k_sweep_shell, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, SA, c->d_src[set], c->d_list[set] + act_off, s);
         c->tm.sweep_launches++;
       }
       HIPCHK(c, hipGetLastError());
@@ -2925,12 +2991,12 @@ static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first,
     hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, 0,
-                       (int *)nullptr, (int *)nullptr, (int *)nullptr, 0);
+                       (int *)nullptr, (int *)nullptr, (int *)nullptr, 0, c->d_stateT);
   else
     hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_chemctl + 2, part);
+                       ndeferred, c->d_chemctl + 2, part, c->d_stateT);
   HIPCHK(c, hipGetLastError());
   c->tm.chem_launches++;
   return 0;
@@ -2987,8 +3053,11 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
     c->tm.chem_launches = 0;
     c->chem_pieces = 0;
+    c->packed_valid = false;
+    c->chem_cells = 0;
     c->chem_dt = dt;
   }
+  c->chem_cells += ncells;
   // Pieces alternate between the two streams: every launch ends in a long thin tail; on alternating streams
   // the next piece fills the chip while the previous one drains.
   hipStream_t st = (c->chem_pieces++ & 1) ? c->stream2 : c->stream;
@@ -3067,6 +3136,11 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     c->tm.chem_ms = ms;
   }
   if (conv_flag) *conv_flag = *c->h_conv;
+  // every cell's products for the next column sweep are up to date if the pieces of this pass covered the mesh
+  // (pieces that overlap or leave gaps, a caller's business, leave the flag down: the next pass then packs anew)
+  // C2R_PACK_AT_PASS_START=1 (diagnostic): never rely on the global pass's copy
+  static const bool pack_always = getenv("C2R_PACK_AT_PASS_START") && atoi(getenv("C2R_PACK_AT_PASS_START")) > 0;
+  c->packed_valid = c->chem_cells == c->g.ncell && !pack_always;
   return 0;
 }
 
@@ -3130,6 +3204,7 @@ static int upload_rates_one(c2r_ctx *c, const double *phih, const double *phihe,
 static int upload_iter_state_one(c2r_ctx *c, const double *xh_av, const double *xhe_av, const double *xh_intermed,
                                      const double *xhe_intermed) {
   if (!c) return 1;
+  c->packed_valid = false;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
   if (xh_av) HIPCHK(c, hipMemcpyAsync(c->d_xh_av, xh_av, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));

@@ -231,6 +231,50 @@ C2R_MHD double log_table_path(const Log10Arg &a, const double *tab, const LogPin
   const double q_ = fma_(r3, p_, s_);
   return q_ + hi_;
 }
+// The same table path with the power of two that __log_fma takes out of x' folded into the table.  x' lies in
+// [0.5, 2), so that power is k in {-1, 0, 1} and, with the 128 intervals of invc / logc, there are 256 cases,
+// numbered E = (hx - 0x3FE00000) >> 13: an entry holds invc, w = fma(k, Ln2hi, logc), c = k * Ln2lo (exact) and k << 20.
+// Against log_table_path this saves, per logarithm, the conversion of k, the fma that makes w and three of the integer
+// operations that find k, the interval and z -- the same bits (fma(k, Ln2lo, lo) == lo + k * Ln2lo for these k).
+struct LogEntry {
+  double invc, w, c;
+  uint32_t kshift, pad;
+};
+C2R_MHD LogEntry make_log_entry(int E) { // E in [0, 256)
+  const double *H = GMT(log_hdr);
+  const int d = E - 0x30;
+  const int i = d & 127, k = d >> 7; // arithmetic shift: -1, 0, 1
+  const double kd = (double)k;
+  LogEntry e;
+  e.invc = GMT(log_tab)[2 * i];
+  e.w = fma_(kd, H[0], GMT(log_tab)[2 * i + 1]);
+  e.c = kd * H[1];
+  e.kshift = (uint32_t)k << 20;
+  e.pad = 0;
+  return e;
+}
+C2R_MHD double log_table_path4(const Log10Arg &a, const LogEntry *tab, const LogPins *pins = nullptr) {
+  const double *A = GMT(log_hdr) + 2;
+  const double A1 = pins ? pins->a1 : A[1], A3 = pins ? pins->a3 : A[3];
+  const uint32_t T = a.hx - 0x3FE00000u;  // [0, 0x200000)
+  const uint32_t off = (T >> 8) & 0x1FE0u; // entry T >> 13 of 32-byte entries
+  const LogEntry *e = (const LogEntry *)((const char *)tab + off);
+  const double invc = e->invc, w = e->w, c = e->c;
+  const uint32_t izh = a.hx - e->kshift;
+  const double z = asdouble(((uint64_t)izh << 32) | a.lo);
+  const double r = fma_(z, invc, -1.0);
+  const double t1 = fma_kc(r, A[2], A1);
+  const double hi_ = r + w;
+  const double r2 = r * r;
+  double lo_ = (w - hi_) + r;
+  lo_ = lo_ + c;
+  const double r3 = r * r2;
+  const double t2 = fma_kc(r, A[4], A3);
+  const double s_ = fma_(r2, A[0], lo_);
+  const double p_ = fma_(t2, r2, t1);
+  const double q_ = fma_(r3, p_, s_);
+  return q_ + hi_;
+}
 // __ieee754_log10's tail: log10(x) from log(x') and the power of two
 C2R_MHD double log10_finish(const Log10Arg &a, double lg) {
   const double ivln10 = asdouble(0x3FDBCB7B1526E50EULL);

@@ -249,4 +249,22 @@ int hh_check_shell_geometry(int smax, int i0, int j0, int k0, int *what) {
   }
   return bad;
 }
+
+// log10 of positive normal numbers through the table path of the restated __log_fma, with the plain (invc, logc)
+// table and with the table that has the power of two folded in (gm::LogEntry, what k_rates keeps in LDS): the
+// arguments outside the near-1 interval must give the same bits.  Returns the number of mismatches.
+int hh_check_log_table4(int n, const double *x) {
+  static gm::LogEntry tab4[256];
+  for (int E = 0; E < 256; E++) tab4[E] = gm::make_log_entry(E);
+  int bad = 0;
+  for (int i = 0; i < n; i++) {
+    const gm::Log10Arg a = gm::log10_split(x[i]);
+    if (gm::log10_near1(a)) continue;
+    const double u = gm::log_table_path(a, gm::log_table()), v = gm::log_table_path4(a, tab4);
+    if (std::memcmp(&u, &v, sizeof u) != 0) bad++;
+    const double f = gm::log10_finish(a, v), g = log10(x[i]);
+    if (std::memcmp(&f, &g, sizeof f) != 0) bad++;
+  }
+  return bad;
+}
 }

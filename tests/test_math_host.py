@@ -65,3 +65,17 @@ def test_division_through_reciprocal_is_correctly_rounded(harness):
     harness.hh_div_recip(a.size, a.ctypes.data_as(dp), b.ctypes.data_as(dp), out.ctypes.data_as(dp))
     with np.errstate(all="ignore"):
         assert np.array_equal(out, a / b)
+
+
+def test_log_table_with_the_power_of_two_folded_in(harness):
+    """gm::log_table_path4 (the 256-entry table k_rates keeps in LDS) against gm::log_table_path and against glibc's
+    log10, 4e6 arguments over the whole range of optical depths and around every table boundary."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    x = np.concatenate([10.0 ** rng.uniform(-20.0, 16.0, 2_000_000), rng.uniform(0.4, 2.2, 1_000_000),
+                        np.ldexp(rng.uniform(0.5, 2.0, 1_000_000), rng.integers(-70, 60, 1_000_000))])
+    # every boundary of the 256 cases, one ulp either side
+    hx = (0x3FE00000 + (np.arange(257, dtype=np.uint64) << np.uint64(13))) << np.uint64(32)
+    edges = np.concatenate([(hx - np.uint64(1)).view(np.float64), hx.view(np.float64)])
+    x = np.ascontiguousarray(np.concatenate([x, edges[np.isfinite(edges) & (edges > 0)]]))
+    assert harness.hh_check_log_table4(C.c_int(len(x)), x.ctypes.data_as(C.POINTER(C.c_double))) == 0

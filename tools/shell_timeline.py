@@ -19,7 +19,7 @@ def main():
     rows = []
     for r in csv.DictReader(open(a.csv)):
         n = r["Kernel_Name"]
-        kind = next((k for k in ("k_sweep_shell", "k_sweep_core", "k_loss_finish", "k_loss", "k_rates", "k_chemistry", "k_transpose_ij") if k in n), None)
+        kind = next((k for k in ("k_sweep_shell", "k_sweep_core", "k_loss_finish", "k_loss", "k_rates", "k_chemistry", "k_transpose_ij", "k_pack_state", "k_transpose_packed") if k in n), None)
         if kind:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, int(r["Grid_Size_X"]), int(r["Grid_Size_Y"])))
     rows.sort()
@@ -27,7 +27,7 @@ def main():
     # a pass starts with k_transpose_ij; the rates and chemistry launches are listed but not part of the sweep
     passes, cur = [], []
     for row in rows:
-        if row[2] == "k_transpose_ij":
+        if row[2] in ("k_transpose_ij", "k_pack_state", "k_transpose_packed"):
             if cur:
                 passes.append(cur)
             cur = []
