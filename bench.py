@@ -37,7 +37,10 @@ EVOLVE0D_BYTES = 136.0                # one source at a time: 40 state + 48 colu
 COLUMN_BYTES_PER_CELL_SOURCE = 88.0   # column sweep alone: 40 B state + 48 B columns
 CHEM_BYTES_PER_CELL = 252.0           # SURVEY.md section 8(d), isothermal chemistry pass
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = ROOT / "profiles" / "r02_bench_pmc_summary.json"
+FP64_PEAK_TFLOPS = 78.6               # MI355X_MICROARCH.md: 16 384 FP64 lanes x 2.4 GHz x 2 (vector; the matrix peak is the same)
+PMC_SUMMARY = next((p for p in (ROOT / "profiles" / f"r{r:02d}_bench_pmc_summary.json" for r in (3, 2)) if p.exists()),
+                   ROOT / "profiles" / "r03_bench_pmc_summary.json")
+DROPIN_TIMING = ROOT / "profiles" / "r03_dropin_timing.json"
 
 
 def rates_bytes_per_launch(cells, nsrc, heating=False):
@@ -292,6 +295,7 @@ def main():
         achieved = rates_bytes / (rates_per_launch_ms * 1e-3) / 1e9
         headline = (not cfg4) and n == 256 and per_gpu == 8 and batch == 8 and not heating and not a.neutral_start
         n_instr = stored_counter("k_rates", "SQ_INSTS_VALU") if headline else None
+        n_flop = stored_counter("k_rates", "fp64_flop_per_launch_upper") if headline else None
         out = {
             "metric": "cell-updates/sec (grid_cells x sources x iters / wall) on 256^3 box; % HBM roofline",
             "value": units / elapsed, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
@@ -326,6 +330,16 @@ def main():
                 "bound": "valu-issue", "unit": "wave-instructions/s", "achieved": n_instr / (rates_per_launch_ms * 1e-3),
                 "peak": 1024 * 2.4e9 / 4.0, "frac": n_instr / (rates_per_launch_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
                 "kernel": "k_rates", "instructions_per_launch": n_instr, "instructions": "stored counter (profiles/), live time"},
+            # "report both HBM % and FP64 %".  FLOPs of one k_rates launch from the stored
+            # SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 counters of this same command (wave-instructions x 64 lanes, an fma
+            # counted twice: an upper bound, lanes masked off in divergent branches included) over the live launch time
+            "roofline_fp64": None if n_flop is None else {
+                "bound": "fp64-vector", "unit": "TFLOP/s", "achieved": n_flop / (rates_per_launch_ms * 1e-3) / 1e12,
+                "peak": FP64_PEAK_TFLOPS, "frac": n_flop / (rates_per_launch_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "kernel": "k_rates", "flop_per_launch": n_flop, "flop_per_cell_source": n_flop / max(1.0, cs_per_launch),
+                "note": "stored counters (profiles/), live time; two thirds of the kernel's vector instructions are FP64 "
+                        "arithmetic, the rest integer / conversion / compare work of the bit-exact log10 and the table "
+                        "look-ups, which is why the issue-rate figure (roofline_valu_issue) is the one that binds"},
             # with a communicator the global pass runs slab by slab behind the sum over ranks, while the rates of
             # later slabs are still being computed: its figure is then the span from the first slab's launch to
             # the end of the last, most of which overlaps the rates
@@ -347,6 +361,16 @@ def main():
             # host time)
             out["per_rank_ms_per_step"] = [1e3 * r["elapsed"] / a.steps for r in allr]
             out["per_rank_kernel_ms_per_step"] = [(r["sweep_ms"] + r["rates_ms"]) / a.steps for r in allr]   # pass only (see above)
+        if headline and DROPIN_TIMING.exists():
+            # the product the north star describes -- the reference's Fortran driver with this library's modules linked
+            # in (oracle/ref_build.sh 256 hip) -- on this very workload, from the reference's own Timings.log stamps
+            # (evolve.F90:150,220); measured by tools/time_dropin.sh on a GPU box and stored (the driver's bench box has
+            # no reference sources to build the binary from)
+            try:
+                dj = json.loads(DROPIN_TIMING.read_text())
+                out["dropin_ms_per_iteration"] = {k: dj[k] for k in ("ms_per_iteration", "iterations", "bench_ms_per_step_same_box", "note") if k in dj}
+            except Exception:
+                pass
         if not a.no_cpu_baseline and world == 1 and not cfg4:
             out["cpu_baseline"] = cpu_baseline(pkg)
             ref = cpu_baseline_reference()

@@ -1,13 +1,21 @@
 set -e
 cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "benchmark_size or config3 or config4 or full_evolve3d or one_iteration" > gpurun_out/ab_tests.log 2>&1 || true
+tail -3 gpurun_out/ab_tests.log
 run() { name=$1; shift; env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err; python - <<PY
 import json
 d=json.load(open('gpurun_out/ab_$name.json'))
 print('$name', round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['kernel_ms_per_step'].items()})
 PY
 }
-for i in 1 2 3; do
-run chem$i A=1
-run start$i C2R_PACK_AT_PASS_START=1
-run generic$i C2R_SWEEP_GENERIC=1
-done
+run tab4_a A=1
+run tab4_b A=1
+python - <<'PY'
+import sys, os
+sys.path.insert(0, os.environ['GRAFT_REPO_ROOT'])
+os.environ['C2R_EXTRA_HIPCC_FLAGS'] = '-DC2R_NO_LOGTAB4'
+import __graft_entry__ as ge
+pkg = ge.load_package(); pkg.build(force=True)
+PY
+run old_a A=1
+run old_b A=1

@@ -10,7 +10,8 @@ import sys
 
 
 def kname(n):
-    for k in ("k_rates", "k_chemistry", "k_sweep_shell", "k_loss_finish", "k_loss_probe", "k_loss", "k_transpose_ij"):
+    for k in ("k_rates", "k_chemistry", "k_sweep_shell_fast", "k_sweep_shell", "k_loss_finish_rounds", "k_loss_finish",
+              "k_loss_probe_rounds", "k_loss_stored", "k_loss", "k_transpose_packed", "k_pack_state", "k_transpose_ij"):
         if k in n:
             return k
     return None
@@ -36,6 +37,11 @@ def main():
             # whose 8-byte-per-lane coalesced reads total 17 doubles per cell): doubled below.
             f, w = res[k]["FETCH_SIZE"]["per_launch"], res[k]["WRITE_SIZE"]["per_launch"]
             res[k]["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
+        fl = [res[k].get("SQ_INSTS_VALU_%s_F64" % n) for n in ("FMA", "MUL", "ADD", "TRANS")]
+        if all(fl):
+            # wave-instructions; a wave64 instruction is 64 lane operations when every lane is active (an upper bound)
+            fma, mul, add, trans = (x["per_launch"] for x in fl)
+            res[k]["fp64_flop_per_launch_upper"] = 64.0 * (2.0 * fma + mul + add + trans)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v.get("hbm_bytes_per_launch_corrected") for k, v in res.items()}, indent=1))
 
