@@ -27,6 +27,13 @@ class Timing(C.Structure):
                 ("cells_swept", C.c_longlong)]
 
 
+class IterationReport(C.Structure):
+    """c2r_iteration_report (include/c2ray_hip.h)."""
+    _fields_ = [("conv_flag", C.c_int), ("sum_nbox", C.c_int), ("photon_loss", C.c_double * NFREQ),
+                ("means_intermed", C.c_double * 5), ("sums_intermed", C.c_double * 5), ("total_rates", C.c_double * 3),
+                ("minima_av", C.c_double * 2), ("reccoef", C.c_double * 12)]
+
+
 class SedSetup(C.Structure):
     """struct c2r_sed_setup (include/c2ray_hip.h)."""
     _fields_ = [("nfreq", C.c_int), ("sed", C.c_int), ("freq_min", _dp), ("delta_freq", _dp), ("xsec_index", _dp),
@@ -97,6 +104,7 @@ SYMBOLS = {
     "c2r_comm_nranks": (C.c_int, [C.c_void_p]),
     "c2r_allreduce_rates": (C.c_int, [C.c_void_p]),
     "c2r_pass_allreduce_chemistry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _ip]),
+    "c2r_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(IterationReport)]),
     "c2r_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "c2r_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
 }

@@ -1155,6 +1155,95 @@ k_stat_finish(const double *__restrict__ partial, int nblocks, double *__restric
   }
 }
 
+// Everything the reference's loop reduces over the grid after a global pass, in one sweep of the arrays
+// (c2r_iteration): v[0..4] = k_state_sums with ndens over (xh_intermed, xhe_intermed), v[5..9] = the same without
+// ndens (the means), v[10..12] = k_total_rates over (xh_av, xhe_av), and the minima of xh_av(0), xhe_av(0).  Every sum
+// runs over the cells in the order of the single-purpose kernels (same grid, same stride, same block tree), so the
+// numbers are theirs bit for bit.  rc_dev: the coefficients the chemistry pass left behind (non-isothermal runs).
+constexpr int ITER_NV = 13;
+__global__ void __launch_bounds__(BLOCK)
+k_iter_stats(size_t nc, RecCoef rc_host, const double *__restrict__ rc_dev, double clumping_scalar,
+             const float *__restrict__ clumping_grid, const double *__restrict__ ndens, const double *__restrict__ xh_int,
+             const double *__restrict__ xhe_int, const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
+             double *__restrict__ partial, double *__restrict__ partial_min) {
+  RecCoef rc = rc_host;
+  if (rc_dev) {
+    rc.arech0 = rc_dev[0]; rc.brech0 = rc_dev[1]; rc.areche0 = rc_dev[2]; rc.breche0 = rc_dev[3]; rc.oreche0 = rc_dev[4];
+    rc.areche1 = rc_dev[5]; rc.breche1 = rc_dev[6]; rc.treche1 = rc_dev[7]; rc.colli_HI = rc_dev[8]; rc.colli_HeI = rc_dev[9];
+    rc.colli_HeII = rc_dev[10]; rc.v = rc_dev[11];
+  }
+  double v[ITER_NV];
+  for (int n = 0; n < ITER_NV; n++) v[n] = 0.0;
+  double a = (double)INFINITY, b = (double)INFINITY;
+  for (size_t q = (size_t)blockIdx.x * BLOCK + threadIdx.x; q < nc; q += (size_t)gridDim.x * BLOCK) {
+    const double nd = ndens[q];
+    const double i0 = xh_int[q], i1 = xh_int[q + nc], j0 = xhe_int[q], j1 = xhe_int[q + nc], j2 = xhe_int[q + 2 * nc];
+    v[0] += nd * i0; v[1] += nd * i1; v[2] += nd * j0; v[3] += nd * j1; v[4] += nd * j2;
+    v[5] += 1.0 * i0; v[6] += 1.0 * i1; v[7] += 1.0 * j0; v[8] += 1.0 * j1; v[9] += 1.0 * j2;
+    const double clumping = clumping_grid ? (double)clumping_grid[q] : clumping_scalar; // photonstatistics.f90:175-177
+    const double yh[2] = {xh_av[q], xh_av[q + nc]};
+    const double yhe[3] = {xhe_av[q], xhe_av[q + nc], xhe_av[q + 2 * nc]};
+    const double de = electrondens(nd, yh, yhe);
+    v[10] += nd * (yh[1] * rc.brech0 * (1.0 - abu_he) + yhe[1] * rc.breche0 * abu_he * 0.04) * de * clumping;
+    v[11] += nd * de * (yh[0] * rc.colli_HI + yhe[0] * rc.colli_HeI + yhe[1] * rc.colli_HeII);
+    v[12] += nd * abu_he * clumping * (yhe[2] * 1.121 * rc.breche1 + yhe[1] * rc.breche0 * 0.96) * abu_he * de;
+    a = dmin(a, yh[0]);
+    b = dmin(b, yhe[0]);
+  }
+  stat_block_reduce<ITER_NV>(v, partial);
+  __shared__ double shm[2][BLOCK / 64];
+  for (int off = 32; off > 0; off >>= 1) {
+    a = dmin(a, __shfl_down(a, off, 64));
+    b = dmin(b, __shfl_down(b, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = a; shm[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double r = shm[threadIdx.x][0];
+    for (int i = 1; i < BLOCK / 64; i++) r = dmin(r, shm[threadIdx.x][i]);
+    partial_min[(size_t)blockIdx.x * 2 + threadIdx.x] = r;
+  }
+}
+// out[0..12] the sums, out[13..14] the minima, out[15..26] the coefficients used
+__global__ void __launch_bounds__(BLOCK)
+k_iter_stats_finish(const double *__restrict__ partial, const double *__restrict__ partial_min, int nblocks, RecCoef rc_host,
+                    const double *__restrict__ rc_dev, double *__restrict__ out) {
+  __shared__ double sh[ITER_NV][BLOCK / 64];
+  __shared__ double shm[2][BLOCK / 64];
+  for (int n = 0; n < ITER_NV; n++) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += BLOCK) x += partial[(size_t)i * ITER_NV + n];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[n][threadIdx.x >> 6] = x;
+  }
+  double a = (double)INFINITY, b = (double)INFINITY;
+  for (int i = threadIdx.x; i < nblocks; i += BLOCK) {
+    a = dmin(a, partial_min[(size_t)i * 2]);
+    b = dmin(b, partial_min[(size_t)i * 2 + 1]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a = dmin(a, __shfl_down(a, off, 64));
+    b = dmin(b, __shfl_down(b, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { shm[0][threadIdx.x >> 6] = a; shm[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x < ITER_NV) {
+    double r = 0.0;
+    for (int i = 0; i < BLOCK / 64; i++) r += sh[threadIdx.x][i];
+    out[threadIdx.x] = r;
+  } else if (threadIdx.x < ITER_NV + 2) {
+    const int m = threadIdx.x - ITER_NV;
+    double r = shm[m][0];
+    for (int i = 1; i < BLOCK / 64; i++) r = dmin(r, shm[m][i]);
+    out[threadIdx.x] = r;
+  } else if (threadIdx.x < ITER_NV + 2 + 12) {
+    const int m = threadIdx.x - ITER_NV - 2;
+    const double h[12] = {rc_host.arech0, rc_host.brech0, rc_host.areche0, rc_host.breche0, rc_host.oreche0, rc_host.areche1,
+                          rc_host.breche1, rc_host.treche1, rc_host.colli_HI, rc_host.colli_HeI, rc_host.colli_HeII, rc_host.v};
+    out[threadIdx.x] = rc_dev ? rc_dev[m] : h[m];
+  }
+}
+
 } // namespace
 
 // =============================================================================================
@@ -1269,6 +1358,9 @@ struct c2r_ctx {
   double *d_rc_last = nullptr;     // 12: coefficients left by the last cell of the chemistry pass
   double *d_stat = nullptr;        // STAT_BLOCKS*5 partials + 8 results
   double *h_stat = nullptr;        // pinned, 8
+  double *d_iter = nullptr;        // k_iter_stats: STAT_BLOCKS*(ITER_NV+2) partials + 32 results
+  double *h_iter = nullptr;        // pinned, 32
+  bool want_iter_stats = false;    // the global pass being closed is followed by k_iter_stats (c2r_iteration)
   double *h_loss = nullptr; // pinned, BATCH_MAX
   int *d_conv = nullptr;
   int *h_conv = nullptr;    // pinned
@@ -1500,6 +1592,8 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMemset(c->d_rc_last, 0, sizeof(double) * 12));
   CR(hipMalloc(&c->d_stat, sizeof(double) * (STAT_BLOCKS * 5 + 8)));
   CR(hipHostMalloc(&c->h_stat, sizeof(double) * 8));
+  CR(hipMalloc(&c->d_iter, sizeof(double) * (STAT_BLOCKS * (ITER_NV + 2) + 32)));
+  CR(hipHostMalloc(&c->h_iter, sizeof(double) * 32));
   c->rates_count = 4 * nc + C2R_NFREQ + 1;
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
@@ -1590,6 +1684,8 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   }
   if (c->h_conv) (void)hipHostFree(c->h_conv);
   if (c->h_stat) (void)hipHostFree(c->h_stat);
+  if (c->h_iter) (void)hipHostFree(c->h_iter);
+  if (c->d_iter) (void)hipFree(c->d_iter);
   for (auto &ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   for (auto &ev : c->ev_pool) (void)hipEventDestroy(ev);
@@ -3128,6 +3224,18 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     c->chem_b1_next = chemistry_ceiling(hist);
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  if (c->want_iter_stats) {
+    // c2r_iteration: the grid reductions the host loop wants after this pass, behind it in the same queue
+    double *partial = c->d_iter, *partial_min = c->d_iter + (size_t)STAT_BLOCKS * ITER_NV, *res = partial_min + (size_t)STAT_BLOCKS * 2;
+    const double *rc_dev = c->isothermal ? nullptr : c->d_rc_last;
+    hipLaunchKernelGGL(k_iter_stats, dim3(STAT_BLOCKS), dim3(BLOCK), 0, c->stream, c->g.ncell, c->sc.rc, rc_dev, c->sc.clumping,
+                       c->clumping_on_grid ? c->d_clump : nullptr, c->d_ndens, c->d_xh_int, c->d_xhe_int, c->d_xh_av, c->d_xhe_av,
+                       partial, partial_min);
+    hipLaunchKernelGGL(k_iter_stats_finish, dim3(1), dim3(BLOCK), 0, c->stream, partial, partial_min, STAT_BLOCKS, c->sc.rc, rc_dev, res);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_iter, res, sizeof(double) * (ITER_NV + 2 + 12), hipMemcpyDeviceToHost, c->stream));
+    c->want_iter_stats = false;
+  }
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->timing) {

@@ -190,6 +190,16 @@ class HipEngine:
         self._chk(self.lib.c2r_pass_allreduce_chemistry(self.h, int(first), int(stride), int(nslab), float(dt), C.byref(cf)))
         return cf.value
 
+    def iteration(self, dt, first=1, stride=1, nslab=4):
+        """c2r_iteration: one outer iteration (pass, sum over ranks, global pass) and every grid reduction the reference's
+        loop reports after it, with one synchronisation; returns the report as a dict of numpy arrays / ints."""
+        rep = _lib.IterationReport()
+        self._chk(self.lib.c2r_iteration(self.h, int(first), int(stride), int(nslab), float(dt), C.byref(rep)))
+        out = {"conv_flag": rep.conv_flag, "sum_nbox": rep.sum_nbox}
+        for k in ("photon_loss", "means_intermed", "sums_intermed", "total_rates", "minima_av", "reccoef"):
+            out[k] = np.array(getattr(rep, k)[:])
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.c2r_destroy(self.h)

@@ -16,6 +16,18 @@ module c2ray_hip
      integer(c_long_long) :: cells_swept
   end type c2r_timing
 
+  !> c2r_iteration_report of include/c2ray_hip.h: what evolve3D's loop reports about one outer iteration
+  type, bind(C) :: c2r_iteration_report
+     integer(c_int) :: conv_flag
+     integer(c_int) :: sum_nbox
+     real(c_double) :: photon_loss(47)
+     real(c_double) :: means_intermed(5)
+     real(c_double) :: sums_intermed(5)
+     real(c_double) :: total_rates(3)
+     real(c_double) :: minima_av(2)
+     real(c_double) :: reccoef(12)
+  end type c2r_iteration_report
+
   !> c2r_sed_setup of include/c2ray_hip.h: what spec_integration starts from for one SED
   type, bind(C) :: c2r_sed_setup
      integer(c_int) :: nfreq, sed
@@ -366,6 +378,14 @@ module c2ray_hip
        real(c_double), value :: dt
        integer(c_int), intent(out) :: conv_flag
      end function c2r_pass_allreduce_chemistry
+
+     integer(c_int) function c2r_iteration(ctx, first, stride, nslab, dt, report) bind(C, name="c2r_iteration")
+       import :: c_int, c_ptr, c_double, c2r_iteration_report
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: first, stride, nslab
+       real(c_double), value :: dt
+       type(c2r_iteration_report), intent(out) :: report
+     end function c2r_iteration
 
      integer(c_int) function c2r_total_rates(ctx, dt, reccoef, out3) bind(C, name="c2r_total_rates")
        import :: c_int, c_ptr, c_double

@@ -77,6 +77,20 @@ module evolve
   real(kind=dp) :: n_before(5)
   !> alternating dump file counter
   integer :: ndump = 0
+  !> One outer iteration as one library call (c2r_iteration: pass, sum over the ranks, global pass and all the
+  !! grid reductions of the log and of calculate_photon_statistics, overlapped where a communicator exists, one
+  !! synchronisation).  C2RAY_HIP_STEPWISE=1 keeps the reference's call-by-call order for every iteration; an
+  !! iteration that writes an iteration dump uses it anyway (the dump holds the state between pass and global pass).
+  logical :: fused_iterations = .true.
+  logical :: fused_settings_read = .false.
+  logical :: loop_timing = .false.
+  integer :: allreduce_slabs = 4
+  !> what c2r_iteration reported about the iteration in flight, for global_pass to log
+  type(c2r_iteration_report) :: report
+  logical :: report_valid = .false.
+  !> minima of xh_av(0), xhe_av(0) as left by the last global pass (the next iteration's "min xh_av" lines)
+  real(kind=dp) :: minima_next(2)
+  logical :: minima_next_valid = .false.
 
 #ifdef MPI
   integer :: mympierror
@@ -97,6 +111,8 @@ contains
     integer :: conv_flag
     integer :: conv_criterion
     integer(kind=8) :: wallclock1, wallclock2, countspersec
+    integer(kind=8) :: loopclock1, loopclock2
+    logical :: dump_due, fused
     integer(c_int) :: iso
     real(kind=dp) :: reccoef(12)
     real(kind=dp) :: n_after(5)
@@ -105,6 +121,9 @@ contains
     call system_clock (wallclock1)
 
     if (.not. tables_uploaded) call upload_tables ()
+    if (.not. fused_settings_read) call read_fused_settings ()
+    minima_next_valid = .false.
+    report_valid = .false.
 
     ! --- host state that changes between calls (cosmo_evol rescales dr, vol, ndens each step)
     iso = 0
@@ -150,6 +169,7 @@ contains
 
     if (rank == 0) write(timefile,"(A,F8.1)") &
          "Time before starting iteration: ", timestamp_wallclock ()
+    call system_clock (loopclock1,countspersec)
 
     do
        if (conv_flag < conv_criterion .and. niter > 1) then
@@ -173,13 +193,21 @@ contains
        LLS_loss = 0.0
 
        if (NumSrc > 0) then
-          call pass_all_sources (niter,dt)
+          ! Is an iteration dump due (every 15 minutes of wall time, evolve.F90:193-203)?  Asked before the pass,
+          ! not after it: the dump holds the state between pass and global pass, so such an iteration goes call by call.
+          call system_clock (wallclock2,countspersec)
+          dump_due = wallclock2-wallclock1 > 15*60*countspersec .or. wallclock2-wallclock1 < 0
+#ifdef MPI
+          call MPI_BCAST (dump_due,1,MPI_LOGICAL,0,MPI_COMM_NEW,mympierror)
+#endif
+          fused = fused_iterations .and. .not.dump_due
+          call pass_all_sources (niter,dt,fused)
 
           if (rank == 0) then
              write(logf,*) "Average number of subboxes: ", real(sum_nbox_all)/real(NumSrc)
              call system_clock (wallclock2,countspersec)
              write(logf,*) "Time and limit are: ", wallclock2-wallclock1, 15.0*60.0*countspersec
-             if (wallclock2-wallclock1 > 15*60*countspersec .or. wallclock2-wallclock1 < 0 ) then
+             if (dump_due) then
                 call write_iteration_dump (niter)
                 wallclock1=wallclock2
              endif
@@ -191,6 +219,11 @@ contains
        if (rank == 0) write(timefile,"(A,I3,A,F8.1)") &
             "Time after iteration ",niter," : ", timestamp_wallclock ()
     enddo
+
+    ! C2RAY_HIP_TIMING=1: the loop's wall time with the clock's own resolution (Timings.log has tenths of a second)
+    call system_clock (loopclock2)
+    if (rank == 0 .and. loop_timing) write(timefile,"(A,I5,A,F12.6,A)") "evolve3D loop: ",niter, &
+         " iterations in ", real(loopclock2-loopclock1,dp)/real(countspersec,dp), " s"
 
     ! --- results back to the modules that own them
     call check (c2r_download_state (hip_ctx, xh, xhe, tptr), "c2r_download_state")
@@ -251,15 +284,36 @@ contains
 
   !----------------------------------------------------------------------------
 
-  subroutine pass_all_sources (niter,dt)
+  subroutine pass_all_sources (niter,dt,fused)
 
     integer,intent(in) :: niter
     real(kind=dp),intent(in) :: dt
+    logical,intent(in) :: fused !< the whole iteration in one library call (see fused_iterations)
 
     integer(c_int) :: nbox
     real(kind=dp) :: tail(NumFreqBnd)
 
     if (rank == 0) write(logf,*) 'Doing all sources '
+
+#if !defined(C2RAY_REFERENCE_DO_GRID) && !defined(C2RAY_GLOBAL_PASS_BY_CELL)
+    if (fused) then
+       ! the "min xh_av" lines of this iteration's global pass show the fractions as they are now
+       if (.not.minima_next_valid) then
+          call check (c2r_fraction_minima (hip_ctx, 2_c_int, minima_next), "c2r_fraction_minima")
+          minima_next_valid = .true.
+       endif
+       ! pass_all_sources, mpi_accumulate_grid_quantities and the global pass with its statistics: the sum over
+       ! the ranks overlaps the pass before it and the chemistry after it, slab by slab; global_pass below
+       ! only writes the log lines
+       call check (c2r_iteration (hip_ctx, int(1+rank,c_int), int(npr,c_int), int(allreduce_slabs,c_int), dt, report), &
+            "c2r_iteration")
+       report_valid = .true.
+       photon_loss_all(:)=report%photon_loss(:)
+       sum_nbox=report%sum_nbox
+       sum_nbox_all=report%sum_nbox
+       return
+    endif
+#endif
 
     ! static distribution of the sources over the ranks: ns = 1+rank, NumSrc, npr
     ! (do_grid_static, master_slave.F90:74-96)
@@ -297,14 +351,36 @@ contains
     ! mean photon loss per cell (evolve.F90:457)
     photon_loss(:)=photon_loss_all(:)/(real(mesh(1))*real(mesh(2))*real(mesh(3)))
 
-    ! Report minimum value of xh_av(0) to check for zeros (evolve.F90:463-466)
+    ! Report minimum value of xh_av(0) to check for zeros (evolve.F90:463-466): of the fractions the global
+    ! pass is about to replace, i.e. as the previous global pass (or the start of the step) left them
     if (rank == 0) then
-       call check (c2r_fraction_minima (hip_ctx, 2_c_int, minima), "c2r_fraction_minima")
+       if (minima_next_valid) then
+          minima=minima_next
+       else
+          call check (c2r_fraction_minima (hip_ctx, 2_c_int, minima), "c2r_fraction_minima")
+       endif
        write(logf,*) "min xh_av: ",minima(1)
        write(logf,*) "min xhe_av: ",minima(2)
     endif
+    minima_next_valid = .false.
 
     if (rank == 0) write(logf,*) 'Doing global '
+    if (report_valid) then
+       ! the iteration has been done (c2r_iteration in pass_all_sources): its numbers, in the reference's order
+       report_valid = .false.
+       conv_flag=report%conv_flag
+       if (rank == 0) then
+          write(logf,*) "Number of non-converged points: ",conv_flag
+          write(logf,*) "Intermediate result for mean H ionization fraction: ", report%means_intermed(2)
+          write(logf,*) "Intermediate result for mean He(+,++) ionization fraction: ", report%means_intermed(4), &
+               report%means_intermed(5)
+       endif
+       minima_next=report%minima_av
+       minima_next_valid = .true.
+       call photon_statistics_from (report%reccoef,report%total_rates,report%sums_intermed)
+       call report_photonstatistics (dt)
+       return
+    endif
 #ifdef C2RAY_GLOBAL_PASS_BY_CELL
     ! the reference's own loop (evolve.F90:477-484) over the per-cell interface of module evolve_point
     conv_flag=0
@@ -362,6 +438,63 @@ contains
     total_ion=dh0+dhe0+dhe2
 
   end subroutine photon_statistics
+
+  ! ===========================================================================
+
+  !> the same from numbers c2r_iteration has already reduced on the device
+  subroutine photon_statistics_from (reccoef,rates3,n_after)
+
+    real(kind=dp),intent(in) :: reccoef(12), rates3(3), n_after(5)
+
+    if (.not.isothermal) then
+       arech0=reccoef(1); brech0=reccoef(2); areche0=reccoef(3); breche0=reccoef(4)
+       oreche0=reccoef(5); areche1=reccoef(6); breche1=reccoef(7); treche1=reccoef(8)
+       colli_HI=reccoef(9); colli_HeI=reccoef(10); colli_HeII=reccoef(11); v=reccoef(12)
+    endif
+    totrec=rates3(1)
+    totcollisions=rates3(2)
+    recomions=rates3(3)
+    dh0=n_before(1)-n_after(1)
+    dhe0=n_before(3)-n_after(3)
+    dhe2=n_after(5)-n_before(5)
+    total_ion=dh0+dhe0+dhe2
+
+  end subroutine photon_statistics_from
+
+  ! ===========================================================================
+
+  !> C2RAY_HIP_STEPWISE, C2RAY_HIP_TIMING, C2R_ALLREDUCE_SLABS
+  subroutine read_fused_settings ()
+
+    character(len=32) :: text
+    integer :: length, status, n
+
+    fused_settings_read = .true.
+    call get_environment_variable ("C2RAY_HIP_STEPWISE", text, length, status)
+    if (status == 0 .and. length > 0) then
+       if (text(1:1) /= "0") fused_iterations = .false.
+    endif
+    call get_environment_variable ("C2RAY_HIP_TIMING", text, length, status)
+    if (status == 0 .and. length > 0) then
+       if (text(1:1) /= "0") loop_timing = .true.
+    endif
+    call get_environment_variable ("C2R_ALLREDUCE_SLABS", text, length, status)
+    if (status == 0 .and. length > 0) then
+       read(text(1:length),*,iostat=status) n
+       if (status == 0 .and. n > 0) allreduce_slabs = n
+    endif
+#if defined(C2RAY_REFERENCE_DO_GRID) || defined(C2RAY_GLOBAL_PASS_BY_CELL)
+    fused_iterations = .false.
+#endif
+    if (rank == 0) then
+       if (fused_iterations) then
+          write(logf,*) "evolve3D: one library call per outer iteration (c2r_iteration)"
+       else
+          write(logf,*) "evolve3D: outer iterations call by call, as the reference's loop"
+       endif
+    endif
+
+  end subroutine read_fused_settings
 
   ! ===========================================================================
 

@@ -270,6 +270,31 @@ int c2r_allreduce_rates(c2r_ctx *ctx);
  * its sum is complete.  conv_flag: non-converged cells (evolve.F90:488). */
 int c2r_pass_allreduce_chemistry(c2r_ctx *ctx, int first, int stride, int nslab, double dt, int *conv_flag);
 
+/* One outer iteration of evolve3D after set_rates_to_zero (files_for_3D/evolve.F90:185-217): pass_all_sources for the
+ * sources first, first + stride, ... (:385-431), mpi_accumulate_grid_quantities (:505-548; a no-op without a
+ * communicator) and global_pass (:435-501) -- c2r_pass_allreduce_chemistry -- followed, in the same queue and
+ * with ONE host synchronisation for all of it, by every grid reduction the reference's loop prints or feeds to
+ * calculate_photon_statistics after a global pass (:463-466, :487-499; photonstatistics.f90:117-234).  The numbers
+ * are those of the single-purpose entry points (same kernels' summation order):
+ *   means_intermed  = c2r_fraction_means(ctx, 1, .)      sums_intermed = c2r_state_sums(ctx, 1, .)
+ *   total_rates     = c2r_total_rates(ctx, dt, reccoef, .) with reccoef = c2r_get_reccoef(ctx, .)
+ *   minima_av       = c2r_fraction_minima(ctx, 2, .) as the NEXT iteration's log lines "min xh_av" / "min xhe_av"
+ *                     will want them (xh_av does not change between a global pass and the next one)
+ *   photon_loss, sum_nbox = c2r_get_loss (summed over the ranks).
+ * A host driver that follows the reference's loop line by line makes six calls with six synchronisations for this;
+ * the Fortran drop-in (fortran/evolve.F90) uses this one unless an iteration dump is due. */
+typedef struct {
+  int conv_flag;
+  int sum_nbox;
+  double photon_loss[C2R_NFREQ];
+  double means_intermed[5];
+  double sums_intermed[5];
+  double total_rates[3];
+  double minima_av[2];
+  double reccoef[12];
+} c2r_iteration_report;
+int c2r_iteration(c2r_ctx *ctx, int first, int stride, int nslab, double dt, c2r_iteration_report *report);
+
 /* Timing of the last c2r_pass_sources / c2r_global_pass on the context's stream, measured with
  * HIP events on that stream: milliseconds spent in the column sweep launches, the rates kernel
  * and the chemistry kernel, and the number of launches of each. */

@@ -47,6 +47,9 @@ def _reference_snapshot(golden_name, run_reference):
     # (c2r_build_tables) instead of uploading rad_ini's host arrays
     (False, "devtables", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     (True, False, [(8, 8, 8, 1e55)]),
+    # C2RAY_HIP_STEPWISE=1: every outer iteration call by call in the reference's order (pass, sum, minima, global pass,
+    # means, state sums, total rates) instead of one c2r_iteration per iteration, which is what all other cases run
+    (False, "stepwise", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     # C2RAY_HIP_FORCE_COMM=1: the shim creates a one-rank RCCL communicator (c2r_comm_unique_id, c2r_comm_init)
     # and every iteration's c2r_allreduce_rates is a real ncclAllReduce
     (False, "comm1", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
@@ -69,12 +72,15 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         monkeypatch.setenv("C2RAY_HIP_SAME_DEVICE", "1")
     comm1, ngpu2 = pl == "comm1", pl == "ngpu2"
     bycell = pl == "bycell"
+    stepwise = pl == "stepwise"
+    if stepwise:
+        monkeypatch.setenv("C2RAY_HIP_STEPWISE", "1")
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
     which_hip = "hip_dogrid" if dogrid else ("hip_bycell" if bycell else "hip")
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "")
     import make_golden_dropin
     if pl:
         assert sources == make_golden_dropin.PL_SOURCES and not iso     # what the fixture was made from
@@ -97,6 +103,10 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         assert "RCCL communicator of one rank" in log2
     if ngpu2:
         assert "devices per rank:   2" in log2
+    if stepwise or dogrid or bycell:
+        assert "outer iterations call by call" in log2
+    else:
+        assert "one library call per outer iteration" in log2
     # the reference's "min xh_av" / "min xhe_av" lines (evolve.F90:463-466), from a device minimum: same numbers
     assert len(s1["mins"]) > 0 and s1["mins"] == s2["mins"]
     # photon statistics (written from host arrays the HIP path filled): compare the numbers

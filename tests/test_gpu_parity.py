@@ -251,6 +251,59 @@ def test_full_size_properties_256(pkg, tables):
     e.close()
 
 
+@pytest.mark.parametrize("fname", ["tap_N16_heat_3src.npz", "tap_N16_iso_1src.npz"])
+def test_iteration_report_equals_the_single_purpose_calls(pkg, tables, gold, fname):
+    """c2r_iteration (one outer iteration and every grid reduction the reference's loop reports after it, one
+    synchronisation) against the same iteration made call by call: c2r_pass_sources, c2r_global_pass,
+    c2r_fraction_means, c2r_state_sums, c2r_get_reccoef, c2r_total_rates, c2r_fraction_minima, c2r_get_loss.  Three
+    iterations each; every number and every grid bit for bit."""
+    import ctypes as C
+    i, _ = tap_case(gold(fname), 1)
+    mesh, mat, grid, src, cosmo = make_inputs(pkg, i)
+    dt = float(i["dt"][0])
+    eng = []
+    for _ in range(2):
+        e = pkg.Evolve(mesh, tables, device=0).engine
+        e.set_step(mat, grid, cosmo)
+        e.set_sources(src)
+        e.upload_state(mat)
+        e.begin_step()
+        eng.append(e)
+    a, b = eng
+    lib = a.lib
+
+    def five(fn, e, which):
+        out = np.empty(5)
+        e._chk(fn(e.h, int(which), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    for it in range(3):
+        a.set_rates_to_zero()
+        a.pass_sources(1, 1)
+        conv = a.global_pass(dt)
+        means = five(lib.c2r_fraction_means, a, 1)
+        sums = a.state_sums(1)
+        rc = a.get_reccoef()
+        rates = a.total_rates(dt, rc)
+        minima = np.empty(2)
+        a._chk(lib.c2r_fraction_minima(a.h, 2, minima.ctypes.data_as(C.POINTER(C.c_double))))
+        loss, nbox = a.get_loss()
+        b.set_rates_to_zero()
+        r = b.iteration(dt)
+        assert r["conv_flag"] == conv and r["sum_nbox"] == nbox, it
+        assert np.array_equal(r["means_intermed"], means), it
+        assert np.array_equal(r["sums_intermed"], sums), it
+        assert np.array_equal(r["reccoef"], rc), it
+        assert np.array_equal(r["total_rates"], rates), it
+        assert np.array_equal(r["minima_av"], minima), it
+        assert np.array_equal(r["photon_loss"], loss), it
+    sa, sb = {**a.download_rates(), **a.download_iter_state()}, {**b.download_rates(), **b.download_iter_state()}
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close()
+    b.close()
+
+
 @pytest.mark.parametrize("fname,call", [("tap_N16_heat_3src.npz", 1), ("tap_N16_iso_1src.npz", 2)])
 def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
     """The grid reductions of photonstatistics.f90 (state_before/after, total_rates) computed on the

@@ -116,3 +116,27 @@ def test_two_ranks_gloo_sources_sharded(pkg, gold):
     n = 16 ** 3
     assert abs(res["xh"][n:].mean() / o["xh"][n:].mean() - 1) < 1e-3
     assert np.max(np.abs(res["xh"] - o["xh"])) < 0.05
+
+
+def test_mpi_lines_of_the_fortran_shim_compile(tmp_path):
+    """The image has no MPI Fortran compiler, so the `#ifdef MPI` lines of the drop-in modules (MPI_BCAST of the RCCL
+    id, of a restart dump and of the dump decision, MPI_ABORT) are never part of a build here.  Compile them all the
+    same: -DMPI with the handful of MPI datatype constants they name given as cpp macros, against the module files of
+    the reference's no-MPI build (whose my_mpi exports rank, npr, MPI_COMM_NEW like the MPI one); MPI_BCAST / MPI_ABORT
+    stay implicit-interface externals, as with mpif.h.  Compile only -- nothing is linked or run."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    fc = "/opt/rocm/lib/llvm/bin/flang"
+    mods = ROOT / "oracle" / "_ref" / "N16"
+    if not Path(fc).exists() or not (mods / "material.mod").exists():
+        pytest.skip("flang or the reference's module files (oracle/ref_build.sh 16) not present")
+    src = ROOT / "c2-ray3dm1d_helium_amd" / "fortran"
+    defs = ["-DMPI", "-DMPI_INTEGER=1", "-DMPI_DOUBLE_PRECISION=2", "-DMPI_REAL=3", "-DMPI_CHARACTER=4", "-DMPI_LOGICAL=5"]
+    for f in ("c2ray_hip_binding.f90", "evolve_data.F90", "evolve_source.F90", "evolve_point.F90", "evolve.F90"):
+        r = subprocess.run([fc, "-cpp", "-O0", "-DGFORT", "-w", *defs, f"-I{mods}", "-c", str(src / f), "-o", str(tmp_path / (f + ".o"))],
+                           cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, f + "\n" + r.stderr[-2000:]
+    # and the lines are really there (an #ifdef that hides nothing proves nothing)
+    text = (src / "evolve.F90").read_text() + (src / "evolve_data.F90").read_text()
+    assert text.count("MPI_BCAST") >= 10 and "MPI_ABORT" in text
