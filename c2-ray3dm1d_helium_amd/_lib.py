@@ -91,6 +91,7 @@ SYMBOLS = {
     "c2r_synchronize": (C.c_int, [C.c_void_p]),
     "c2r_set_batch": (C.c_int, [C.c_void_p, C.c_int]),
     "c2r_evolve0d_global": (C.c_int, [C.c_void_p, C.c_double, _ip, _ip]),
+    "c2r_evolve0d": (C.c_int, [C.c_void_p, _ip, C.c_int, C.c_int, C.c_int, _dp]),
     "c2r_fraction_minima": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "c2r_get_constants": (C.c_int, [_dp, C.c_int]),
     "c2r_device_count": (C.c_int, []),

@@ -1155,6 +1155,59 @@ k_stat_finish(const double *__restrict__ partial, int nblocks, double *__restric
   }
 }
 
+// evolve0D for one cell and one source (c2r_evolve0d): the column part (sweep_cell) and the rates part (as k_rates
+// for one source) in one thread, the loss through the cell if the caller says it lies on its sub-box's surface.
+template <bool HEAT, bool MULTI>
+__global__ void __launch_bounds__(64)
+k_evolve0d(SweepArgs A, SrcDev S, int di, int dj, int dk, const BandData *__restrict__ bd, SedSet ss, double *__restrict__ rates,
+           double *__restrict__ loss_out) {
+  if (threadIdx.x != 0) return;
+  const Grid &g = A.g;
+  const size_t nc = g.ncell;
+  const int ia = di < 0 ? -di : di, ja = dj < 0 ? -dj : dj, ka = dk < 0 ? -dk : dk;
+  const int shell = ia > ja ? (ia > ka ? ia : ka) : (ja > ka ? ja : ka);
+  const size_t p = shell_position(di, dj, dk);
+  sweep_cell(A, S, shell, (int)(p - (size_t)shell_offset(shell)));
+  __threadfence_block();
+  const global_double *cs = (const global_double *)S.cols;
+  const size_t cz = S.cz;
+  const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
+  const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
+  const int i = wrap0(S.i0 - 1 + di, g.n1), j = wrap0(S.j0 - 1 + dj, g.n2), k = wrap0(S.k0 - 1 + dk, g.n3);
+  const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+  const double nd = A.ndens[q];
+  const double h0 = dmax(A.xh_av[q], epsilon), h1 = dmax(A.xh_av[q + nc], epsilon);
+  const double he0 = dmax(A.xhe_av[q], epsilon), he1 = dmax(A.xhe_av[q + nc], epsilon);
+  double vol_ph;
+  if (shell == 0) {
+    vol_ph = A.sc.dr1 * A.sc.dr2 * A.sc.dr3;
+  } else {
+    const double path = sc_path(di, dj, dk) * A.sc.dr1;
+    const double xs = A.sc.dr1 * (double)di, ys = A.sc.dr2 * (double)dj, zs = A.sc.dr3 * (double)dk;
+    const double dist2 = xs * xs + ys * ys + zs * zs;
+    vol_ph = 4.0 * pi * dist2 * path;
+  }
+  double photo_out = 0.0;
+  if (cin_HI < max_coldensh) {
+    Ricotti ric = {};
+    if (HEAT) ric = ricotti_parameters(h1);
+    PhotoOut o;
+    if (MULTI) {
+      const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
+      photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o);
+    } else {
+      photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI, cin_HeI,
+                           cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o);
+    }
+    rates[q] = rates[q] + o.photo_HI / (h0 * nd * (1.0 - abu_he));
+    rates[q + nc] = rates[q + nc] + o.photo_HeI / (he0 * nd * abu_he);
+    rates[q + 2 * nc] = rates[q + 2 * nc] + o.photo_HeII / (he1 * nd * abu_he);
+    if (HEAT) rates[q + 3 * nc] = rates[q + 3 * nc] + o.heat;
+    photo_out = o.photo_out;
+  }
+  if (loss_out) *loss_out = photo_out * A.sc.vol / vol_ph;
+}
+
 // Everything the reference's loop reduces over the grid after a global pass, in one sweep of the arrays
 // (c2r_iteration): v[0..4] = k_state_sums with ndens over (xh_intermed, xhe_intermed), v[5..9] = the same without
 // ndens (the means), v[10..12] = k_total_rates over (xh_av, xhe_av), and the minima of xh_av(0), xhe_av(0).  Every sum
@@ -1360,6 +1413,10 @@ struct c2r_ctx {
   double *h_stat = nullptr;        // pinned, 8
   double *d_iter = nullptr;        // k_iter_stats: STAT_BLOCKS*(ITER_NV+2) partials + 32 results
   double *h_iter = nullptr;        // pinned, 32
+  // c2r_evolve0d: the column block of the source being traced cell by cell, and which source that is
+  double *d_point_cols = nullptr;
+  int point_ns = 0, point_niter = 0;
+  double *d_point_loss = nullptr, *h_point_loss = nullptr;
   bool want_iter_stats = false;    // the global pass being closed is followed by k_iter_stats (c2r_iteration)
   double *h_loss = nullptr; // pinned, BATCH_MAX
   int *d_conv = nullptr;
@@ -1685,6 +1742,9 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   if (c->h_conv) (void)hipHostFree(c->h_conv);
   if (c->h_stat) (void)hipHostFree(c->h_stat);
   if (c->h_iter) (void)hipHostFree(c->h_iter);
+  if (c->h_point_loss) (void)hipHostFree(c->h_point_loss);
+  if (c->d_point_loss) (void)hipFree(c->d_point_loss);
+  if (c->d_point_cols) (void)hipFree(c->d_point_cols);
   if (c->d_iter) (void)hipFree(c->d_iter);
   for (auto &ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -3128,6 +3188,67 @@ extern "C" int c2r_evolve0d_global(c2r_ctx *c, double dt, const int pos[3], int 
   if (conv_flag) *conv_flag += *c->h_conv;
   for (c2r_ctx *r : c->replicas) // the other devices of a multi-device context keep the same state
     if (c2r_evolve0d_global(r, dt, pos, nullptr)) { c->err = r->err; return 1; }
+  return 0;
+}
+
+// evolve0D(dt,rtpos,ns,niter) for one cell (see the header): one small launch per call, in the caller's order
+extern "C" int c2r_evolve0d(c2r_ctx *c, const int rtpos[3], int ns, int niter, int on_surface, double *loss) {
+  if (!c || !rtpos) return 1;
+  if (!c->replicas.empty()) return fail(c, "c2r_evolve0d: not available on a multi-device context");
+  if (check_ready(c, "c2r_evolve0d")) return 1;
+  if (ns < 1 || ns > c->nsrc) return fail(c, "c2r_evolve0d: source %d not in [1,%d]", ns, c->nsrc);
+  if (c->pass_open) return fail(c, "c2r_evolve0d: a pass opened by c2r_pass_sources_begin is still open");
+  HIPCHK(c, hipSetDevice(c->device));
+  const Grid g = c->g;
+  const int *sp = &c->srcpos[3 * (size_t)(ns - 1)];
+  const int di = rtpos[0] - sp[0], dj = rtpos[1] - sp[1], dk = rtpos[2] - sp[2];
+  const Reach R = mesh_reach(g);
+  if (di < R.l[0] || di > R.r[0] || dj < R.l[1] || dj > R.r[1] || dk < R.l[2] || dk > R.r[2])
+    return fail(c, "c2r_evolve0d: cell (%d,%d,%d) is beyond the reach of source %d at (%d,%d,%d)", rtpos[0], rtpos[1], rtpos[2], ns,
+                sp[0], sp[1], sp[2]);
+  if (flush_rates_zero(c)) return 1;
+  const size_t w = (size_t)(2 * g.smax + 1), cz = w * w * w;
+  if (!c->d_point_cols) {
+    // a block that holds the whole mesh, zeroed once: only ever finite columns afterwards (see the arena)
+    HIPCHK(c, hipMalloc(&c->d_point_cols, sizeof(double) * 6 * cz));
+    HIPCHK(c, zero_device(c->d_point_cols, sizeof(double) * 6 * cz, c->stream));
+    HIPCHK(c, hipMalloc(&c->d_point_loss, sizeof(double)));
+    HIPCHK(c, hipHostMalloc(&c->h_point_loss, sizeof(double)));
+  }
+  c->point_ns = ns;
+  c->point_niter = niter;
+  const StepScalars sc = scalars(c);
+  bool multi = false;
+  const SedSet ss = sedset(c, &multi);
+  SweepArgs SA;
+  SA.g = g; SA.sc = sc;
+  for (int d = 0; d < 3; d++) { SA.box.lo[d] = R.l[d]; SA.box.hi[d] = R.r[d]; }
+  SA.ndens = c->d_ndens; SA.xh_av = c->d_xh_av; SA.xhe_av = c->d_xhe_av;
+  SA.packed = SA.packedT = nullptr;
+  SA.lls_grid = c->lls_on_grid ? c->d_lls : nullptr;
+  SrcDev S{};
+  S.i0 = sp[0]; S.j0 = sp[1]; S.k0 = sp[2];
+  S.nflux = c->normflux[(size_t)ns - 1];
+  for (int k = 0; k < 2; k++) S.nflux_sed[k] = c->normflux_sed[k].empty() ? 0.0 : c->normflux_sed[k][(size_t)ns - 1];
+  S.cols = c->d_point_cols;
+  S.cz = cz;
+  S.loss_lo = -1;
+  double *dl = on_surface ? c->d_point_loss : nullptr;
+  if (!c->isothermal) c->phiheat_dirty = true;
+#define C2R_LAUNCH_POINT(H, M) \
+  hipLaunchKernelGGL((k_evolve0d<H, M>), dim3(1), dim3(64), 0, c->stream, SA, S, di, dj, dk, c->d_bands, ss, c->d_rates, dl)
+  if (c->isothermal) {
+    if (multi) C2R_LAUNCH_POINT(false, true); else C2R_LAUNCH_POINT(false, false);
+  } else {
+    if (multi) C2R_LAUNCH_POINT(true, true); else C2R_LAUNCH_POINT(true, false);
+  }
+#undef C2R_LAUNCH_POINT
+  HIPCHK(c, hipGetLastError());
+  if (on_surface) {
+    HIPCHK(c, hipMemcpyAsync(c->h_point_loss, c->d_point_loss, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (loss) *loss = *c->h_point_loss;
+  }
   return 0;
 }
 

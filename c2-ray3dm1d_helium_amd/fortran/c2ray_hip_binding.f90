@@ -379,6 +379,14 @@ module c2ray_hip
        integer(c_int), intent(out) :: conv_flag
      end function c2r_pass_allreduce_chemistry
 
+     integer(c_int) function c2r_evolve0d(ctx, rtpos, ns, niter, on_surface, loss) bind(C, name="c2r_evolve0d")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(in) :: rtpos(3)
+       integer(c_int), value :: ns, niter, on_surface
+       real(c_double), intent(out) :: loss
+     end function c2r_evolve0d
+
      integer(c_int) function c2r_iteration(ctx, first, stride, nslab, dt, report) bind(C, name="c2r_iteration")
        import :: c_int, c_ptr, c_double, c2r_iteration_report
        type(c_ptr), value :: ctx

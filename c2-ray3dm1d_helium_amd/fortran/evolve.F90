@@ -190,6 +190,7 @@ contains
        niter=niter+1
 
        call check (c2r_set_rates_to_zero (hip_ctx), "c2r_set_rates_to_zero")
+       photon_loss(:)=0.0
        LLS_loss = 0.0
 
        if (NumSrc > 0) then
@@ -318,6 +319,9 @@ contains
     ! static distribution of the sources over the ranks: ns = 1+rank, NumSrc, npr
     ! (do_grid_static, master_slave.F90:74-96)
 #ifdef C2RAY_REFERENCE_DO_GRID
+#ifdef C2RAY_REFERENCE_DO_SOURCE
+    sum_nbox=0
+#endif
     call do_grid (dt,niter)
 #else
     call check (c2r_pass_sources (hip_ctx, int(1+rank,c_int), int(npr,c_int)), "c2r_pass_sources")
@@ -327,10 +331,17 @@ contains
     ! and sum_nbox, device to device, over the GPUs of all ranks (nothing to do for one GPU); afterwards
     ! c2r_get_loss returns the sums
     call check (c2r_allreduce_rates (hip_ctx), "c2r_allreduce_rates")
+#ifdef C2RAY_REFERENCE_DO_SOURCE
+    ! the reference's own do_source (on this library's evolve0D) has kept the books on the host
+    ! (evolve_source.F90:233-236), as in the reference's pass_all_sources without MPI (evolve.F90:423-426)
+    photon_loss_all(:)=photon_loss(:)
+    sum_nbox_all=sum_nbox
+#else
     call check (c2r_get_loss (hip_ctx, tail, nbox), "c2r_get_loss")
     photon_loss_all(:)=tail(:)
     sum_nbox=nbox
     sum_nbox_all=nbox
+#endif
 
   end subroutine pass_all_sources
 
@@ -502,11 +513,17 @@ contains
   subroutine download_rates ()
 
     integer(c_int) :: nbox
+#ifdef C2RAY_REFERENCE_DO_SOURCE
+    real(kind=dp) :: tail(NumFreqBnd)
+
+    call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, tail, nbox), "c2r_download_rates")
+#else
 
     call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
          "c2r_download_rates")
     sum_nbox=nbox
     sum_nbox_all=nbox
+#endif
 
   end subroutine download_rates
 

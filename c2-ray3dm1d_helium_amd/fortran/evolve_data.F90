@@ -37,6 +37,17 @@ module evolve_data
   !> photons that left the mesh, per frequency band, summed over sources (and ranks)
   real(kind=dp) :: photon_loss_all(NumFreqBnd)
 
+  ! What the reference's own do_source (files_for_3D/evolve_source.F90, linked unmodified on top of this library's
+  ! evolve0D: the cell-by-cell interface, INTEGRATION.md) keeps in this module.  The columns themselves live on the
+  ! device; coldensh_out only carries the reference's "this cell has been done for this source" mark (do_source
+  ! zeroes it per source, evolve0D tests it).  Allocated when C2RAY_HIP_POINT_INTERFACE=1.
+  integer :: tn=1 !< thread number
+  real(kind=dp),dimension(:,:,:),allocatable :: coldensh_out
+  real(kind=dp),dimension(:,:,:,:),allocatable :: coldenshe_out
+  real(kind=dp),dimension(:),allocatable :: photon_loss_src_thread
+  integer,dimension(Ndim) :: last_l !< mesh position of left end point for RT
+  integer,dimension(Ndim) :: last_r !< mesh position of right end point for RT
+
   !> The device context (include/c2ray_hip.h): the GPU(s) of this rank
   type(c_ptr) :: hip_ctx = c_null_ptr
   !> first GPU used by this rank, and how many it drives (C2RAY_HIP_NGPU > 1: one process, several GPUs)
@@ -67,6 +78,16 @@ contains
     allocate(xh_av(n1,n2,n3,0:1), xh_intermed(n1,n2,n3,0:1))
     allocate(xhe_av(n1,n2,n3,0:2), xhe_intermed(n1,n2,n3,0:2))
     photon_loss_all(:) = 0.0_dp
+
+    call get_environment_variable ("C2RAY_HIP_POINT_INTERFACE", value, length, status)
+    if (status == 0 .and. length > 0) then
+       if (value(1:1) /= "0") then
+          allocate(coldensh_out(n1,n2,n3), coldenshe_out(n1,n2,n3,0:1), photon_loss_src_thread(1))
+          coldensh_out(:,:,:) = 0.0_dp
+          coldenshe_out(:,:,:,:) = 0.0_dp
+          photon_loss_src_thread(:) = 0.0_dp
+       endif
+    endif
 
     call check_compiled_constants ()
 

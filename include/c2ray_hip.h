@@ -270,6 +270,19 @@ int c2r_allreduce_rates(c2r_ctx *ctx);
  * its sum is complete.  conv_flag: non-converged cells (evolve.F90:488). */
 int c2r_pass_allreduce_chemistry(c2r_ctx *ctx, int first, int stride, int nslab, double dt, int *conv_flag);
 
+/* evolve0D(dt,rtpos,ns,niter) (files_for_3D/evolve_point.F90:79-319) for ONE cell, for hosts that drive the sweep
+ * themselves, cell by cell, as the reference's do_source does through evolve2D / evolve1D_axis / evolve2D_plane /
+ * evolve3D_quadrant (files_for_3D/evolve_source.F90:244-608): the incoming columns of the cell at mesh position rtpos
+ * (1-based, not wrapped: rtpos - srcpos(:,ns) is the offset from the source) by short characteristics from the cells
+ * of source ns done before it, its own columns, its photo-ionisation (and heating) rates added to the rate grids.
+ * The caller keeps the order of the reference's sweeps (a cell after the cells it interpolates from) and the
+ * reference's "already done" test (coldensh_out(pos) == 0): every cell of a source is given once.  A new (ns, niter)
+ * pair starts a new source.  on_surface != 0: the cell lies on the surface of the caller's current sub-box
+ * (evolve_point.F90:310-315); *loss then receives phi%photo_out * vol / vol_ph, for which the call waits for the
+ * device -- all other calls only queue work.  One launch per cell: an interface for the reference's own loops, tests
+ * and small meshes; c2r_do_source / c2r_pass_sources trace a source as a whole. */
+int c2r_evolve0d(c2r_ctx *ctx, const int rtpos[3], int ns, int niter, int on_surface, double *loss);
+
 /* One outer iteration of evolve3D after set_rates_to_zero (files_for_3D/evolve.F90:185-217): pass_all_sources for the
  * sources first, first + stride, ... (:385-431), mpi_accumulate_grid_quantities (:505-548; a no-op without a
  * communicator) and global_pass (:435-501) -- c2r_pass_allreduce_chemistry -- followed, in the same queue and

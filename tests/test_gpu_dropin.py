@@ -43,6 +43,10 @@ def _reference_snapshot(golden_name, run_reference):
     # C2Ray_3D_hip_bycell: the global pass through the per-cell interface of the product's module evolve_point
     # (evolve0D_global for every cell, the reference's own loop)
     (False, "bycell", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
+    # C2Ray_3D_hip_bypoint: the reference's own evolve_source.F90 and master_slave.F90 (both unmodified) on top of the
+    # per-cell interface of the product's module evolve_point: evolve0D(dt,rtpos,ns,niter) for every cell of every
+    # sub-box, in the order of the reference's evolve2D sweeps (c2r_evolve0d, one launch per cell)
+    (False, "bypoint", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
     # C2RAY_HIP_BUILD_TABLES=1: the shim has the photo-ionisation / heating tables integrated on the device
     # (c2r_build_tables) instead of uploading rad_ini's host arrays
     (False, "devtables", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
@@ -72,15 +76,18 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         monkeypatch.setenv("C2RAY_HIP_SAME_DEVICE", "1")
     comm1, ngpu2 = pl == "comm1", pl == "ngpu2"
     bycell = pl == "bycell"
+    bypoint = pl == "bypoint"
+    if bypoint:
+        monkeypatch.setenv("C2RAY_HIP_POINT_INTERFACE", "1")
     stepwise = pl == "stepwise"
     if stepwise:
         monkeypatch.setenv("C2RAY_HIP_STEPWISE", "1")
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
-    which_hip = "hip_dogrid" if dogrid else ("hip_bycell" if bycell else "hip")
+    which_hip = "hip_dogrid" if dogrid else ("hip_bycell" if bycell else ("hip_bypoint" if bypoint else "hip"))
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "")
     import make_golden_dropin
     if pl:
         assert sources == make_golden_dropin.PL_SOURCES and not iso     # what the fixture was made from
@@ -103,7 +110,7 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         assert "RCCL communicator of one rank" in log2
     if ngpu2:
         assert "devices per rank:   2" in log2
-    if stepwise or dogrid or bycell:
+    if stepwise or dogrid or bycell or bypoint:
         assert "outer iterations call by call" in log2
     else:
         assert "one library call per outer iteration" in log2

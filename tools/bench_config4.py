@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--correlated", type=float, default=0.0, metavar="INDEX",
                     help="log-density with power spectrum k^-INDEX (e.g. 2.5) instead of white noise: neighbouring cells alike")
     ap.add_argument("--headline", action="store_true", help="bench.py's workload instead (256^3, 8 bright sources, pre-ionised gas): for --lane-census")
+    ap.add_argument("--all-ranks", action="store_true",
+                    help="play ALL --ranks ranks one after another on this GPU in every iteration (their rates add up in the one set of "
+                         "rate grids, then one global pass): the full problem's ionisation history, and every rank's share of "
+                         "each pass timed separately -- what decides the scaling of the sharded run")
     ap.add_argument("--lane-census", action="store_true",
                     help="library built with -DC2R_RATES_COUNT: per iteration, how well k_rates' band loop fills its lanes")
     a = ap.parse_args()
@@ -142,7 +146,16 @@ def main():
         niter += 1
         t0 = time.perf_counter()
         e.set_rates_to_zero()
-        e.pass_sources(1 + a.rank, a.ranks)
+        shares = []
+        if a.all_ranks:
+            for r in range(a.ranks):
+                ta = time.perf_counter()
+                e.pass_sources(1 + r, a.ranks)
+                tmr = e.timing()
+                shares.append({"rank": r, "pass_ms": 1e3 * (time.perf_counter() - ta), "sweep_kernel_ms": tmr.sweep_ms,
+                               "rates_kernel_ms": tmr.rates_ms, "cells_swept": int(tmr.cells_swept)})
+        else:
+            e.pass_sources(1 + a.rank, a.ranks)
         t1 = time.perf_counter()
         conv = e.global_pass(dt)
         t2 = time.perf_counter()
@@ -153,6 +166,11 @@ def main():
                      "rates_launches": tm.rates_launches, "nonconv": int(conv), "sum_nbox": int(e.get_loss()[1])})
         if census:
             hist[-1]["lane_census"] = census
+        if shares:
+            p = [x["pass_ms"] for x in shares]
+            hist[-1]["rank_shares"] = shares
+            hist[-1]["share_max_ms"], hist[-1]["share_mean_ms"] = max(p), sum(p) / len(p)
+            hist[-1]["share_max_over_mean"] = max(p) / (sum(p) / len(p))
     wall = time.perf_counter() - t_all
     swept = sum(h["cells_swept"] for h in hist)
     out = {"tables_s": t_tab,
@@ -162,6 +180,22 @@ def main():
            "nominal_cell_updates_per_s": n ** 3 * mine * niter / wall,
            "mean_subboxes_per_source": float(np.mean([h["sum_nbox"] for h in hist])) / max(1, mine),
            "iterations": hist}
+    if a.all_ranks:
+        # what an N-GPU step would take: the slowest share, the sum over the ranks (403 MB of rate grids at 256^3,
+        # isothermal; ring all-reduce over xGMI, 2 (N-1)/N x bytes at the per-link rate of MI355X_MICROARCH.md --
+        # the slab pipeline hides part of it behind the pass and the chemistry) and the replicated chemistry.
+        # A PREDICTION from one GPU's timings, not a measurement.
+        bytes_sum = (3 if not a.heating else 4) * n ** 3 * 8.0
+        link_gbs = 153.0 * 0.8
+        allreduce_ms = 1e3 * 2.0 * (a.ranks - 1) / a.ranks * bytes_sum / (link_gbs * 1e9 * min(7, a.ranks - 1)) if a.ranks > 1 else 0.0
+        pred = []
+        for h in hist:
+            one_gpu = sum(x["pass_ms"] for x in h["rank_shares"]) + h["chem_ms"]
+            step = h["share_max_ms"] + allreduce_ms + h["chem_ms"]
+            pred.append({"iter": h["iter"], "one_gpu_ms": one_gpu, "predicted_step_ms": step, "predicted_speedup": one_gpu / step})
+        out["prediction"] = {"label": "PREDICTED from one GPU's per-share timings, not measured on N GPUs",
+                             "allreduce_ms_exposed_upper": allreduce_ms, "per_iteration": pred,
+                             "share_max_over_mean": [h["share_max_over_mean"] for h in hist]}
     print(json.dumps(out))
     e.close()
 
