@@ -29,6 +29,7 @@
 #define C2R_MATH_EXP(x) exp(x)
 #define C2R_MATH_LOG10(x) log10(x)
 #define C2R_MATH_LOG10P(x) log10(x)
+#define C2R_MATH_LOG10PT(x, tab) log10(x)
 #define C2R_MATH_LOG10N(x) log10(x)
 #define C2R_MATH_POW(x, y) pow(x, y)
 #endif
@@ -330,9 +331,10 @@ C2R_HD void doric(double dt, double rhe, IonStates &ion, double phi_HI, double p
 }
 
 // cooling_h.f90:40-71; cool = 5 x 801 linear curves (h0, h1, he0, he1, he2)
+// `logtab`: the (invc, logc) table of the bit-exact log, wherever the caller keeps it (null: the global one)
 C2R_HD double coolin(const double *cool, double mintemp, double dtemp, double nucldens, double eldens,
-                     const double *xh, const double *xhe, double temp0) {
-  double tpos = (C2R_MATH_LOG10P(temp0) - mintemp) / dtemp + 1.0;
+                     const double *xh, const double *xhe, double temp0, const double *logtab = nullptr) {
+  double tpos = ((logtab ? C2R_MATH_LOG10PT(temp0, logtab) : C2R_MATH_LOG10P(temp0)) - mintemp) / dtemp + 1.0;
   int itpos = (int)tpos;
   itpos = itpos < 1 ? 1 : itpos;
   itpos = itpos > NCOOL - 1 ? NCOOL - 1 : itpos;
@@ -358,6 +360,7 @@ struct CoolData {
   const double *cool;
   double mintemp, dtemp;
   double zred, H0, Omega0;
+  const double *logtab; // see coolin; may be null
 };
 
 // thermal.f90:22-174 (cosmological = .true.)
@@ -381,7 +384,7 @@ C2R_HD bool thermal(const CoolData &cd, double dt, double &end_temper, double &a
         if (++(*work) > budget && budget) return true;
       }
       double cooling =
-          coolin(cd.cool, cd.mintemp, cd.dtemp, ndens_atom, ndens_electron, ion.h_av, ion.he_av, end_temper) +
+          coolin(cd.cool, cd.mintemp, cd.dtemp, ndens_atom, ndens_electron, ion.h_av, ion.he_av, end_temper, cd.logtab) +
           cosmo_cool_rate;
       double thermal_rate = dmax(1e-50, fabs(cooling - heating));
       double thermal_timescale = internal_energy / fabs(thermal_rate);

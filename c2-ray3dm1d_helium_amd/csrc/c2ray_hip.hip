@@ -826,33 +826,48 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
 
 // ---------------------------------------------------------------------------------------------
 // evolve0D_global + do_chemistry (files_for_3D/evolve_point.F90:325-440, :444-646), one cell per lane.
+constexpr int CHEM_HIST = 24; // buckets of the histogram of thermal sub-steps per cell (powers of two)
 #ifndef C2R_CHEM_BLOCK
 #define C2R_CHEM_BLOCK 64
 #endif
 #ifndef C2R_CHEM_WAVES
 #define C2R_CHEM_WAVES 2
 #endif
-template <bool HEAT>
-__global__ void __launch_bounds__(C2R_CHEM_BLOCK, C2R_CHEM_WAVES)
+// LDSTAB (heating only): the five cooling curves (32 KB) and the log's table (2 KB) in LDS.  A thermal sub-step is one
+// long chain of dependent operations, two of whose links are memory round trips -- the table of log10(T), then ten
+// cooling-curve entries -- and with two waves per SIMD nothing hides them: from LDS they cost a sixth.  Filling 34 KB
+// per block only pays for cells known to sub-cycle, so the first launch of a pass, where most cells are done after
+// a handful of sub-steps, reads the tables from global memory and the repacked tiers after it use this variant;
+// blocks are two waves there, so that eight waves per compute unit still fit beside 4 x 34 KB.
+constexpr int CHEM_BLOCK_LDS = 128;
+template <bool HEAT, bool LDSTAB = false>
+__global__ void __launch_bounds__(LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK, C2R_CHEM_WAVES)
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
             const float *__restrict__ clumping_grid, size_t q_first, size_t q_end, const int *__restrict__ list,
-            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist, int part,
+            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist,
             double *__restrict__ packed) {
   // Cells are taken from the range [q_first, q_end) or, when `list` is given, from list[q_first .. q_end).
   // Heating runs (hist != null): budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps --
   // nothing of it is stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds
   // only such cells (c2r_global_pass_finish).  hist counts the cells per power of two of sub-steps.
-  // part 0: every block; part 1: only every 64th block (the sample a heating pass starts with, launched with a
-  // 64 times smaller grid); part 2: all the others.
   const size_t nc = g.ncell;
-  const size_t blk = part == 1 ? (size_t)blockIdx.x * 64 : (size_t)blockIdx.x;
-  const size_t idx = q_first + blk * C2R_CHEM_BLOCK + threadIdx.x;
+  __shared__ double s_cool[LDSTAB ? 5 * NCOOL : 1];
+  __shared__ double s_log[LDSTAB ? 256 : 1];
+  if (LDSTAB) {
+    for (int n = (int)threadIdx.x; n < 5 * NCOOL; n += CHEM_BLOCK_LDS) s_cool[n] = sc.cd.cool[n];
+    for (int n = (int)threadIdx.x; n < 256; n += CHEM_BLOCK_LDS) s_log[n] = gm::log_table()[n];
+    __syncthreads();
+    sc.cd.cool = s_cool;
+    sc.cd.logtab = s_log;
+  }
+  const size_t idx = q_first + (size_t)blockIdx.x * (LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK) + threadIdx.x;
   int notconv = 0;
   int bucket = -1;
-  if (idx < q_end && !(part == 2 && (blk & 63) == 0)) {
+  int work_done = 0, nit_done = 0;
+  if (idx < q_end) {
     const size_t q = list ? (size_t)list[idx] : idx;
     int work = 0;
     bool dropped = false;
@@ -935,6 +950,8 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
       deferred[atomicAdd(ndeferred, 1)] = (int)q;
     } else {
     if (HEAT && hist) bucket = work > 0 ? 32 - __clz(work) : 0;
+    work_done = work;
+    nit_done = nit;
     // The reference keeps the coefficients in module-global variables (cgsconstants.f90:106-133): after
     // the global pass they hold what the LAST cell (mesh,mesh,mesh) computed last, and
     // photonstatistics:total_rates then uses those for every cell.  Export them for the host.
@@ -968,6 +985,19 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
     packed[q + nc] = dmax(ion.he_av[0], epsilon) * ndens_p;
     packed[q + 2 * nc] = dmax(ion.he_av[1], epsilon) * ndens_p;
     } // not dropped
+  }
+  if (HEAT && hist) {
+    // the longest chain of the launch: most thermal sub-steps and most do_chemistry iterations of one cell
+    // (hist[CHEM_HIST], hist[CHEM_HIST + 1]; diagnostics, C2R_CHEM_LOG)
+    int wmax = bucket >= 0 ? work_done : 0, nmax = bucket >= 0 ? nit_done : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+      wmax = max(wmax, __shfl_xor(wmax, off, 64));
+      nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (wmax > 0) atomicMax(&hist[CHEM_HIST], wmax);
+      if (nmax > 0) atomicMax(&hist[CHEM_HIST + 1], nmax);
+    }
   }
   if (HEAT && hist) { // one atomic per wave and distinct bucket
     unsigned long long live = __ballot(bucket >= 0);
@@ -1442,10 +1472,6 @@ struct c2r_ctx {
 
   int chem_pieces = 0;              // pieces of the open global pass (c2r_global_pass_cells)
   double chem_dt = 0.0;
-  int chem_b1 = 0;                  // sub-step ceiling of the open heating global pass's first launch (0: none)
-  int chem_b1_next = 0;             // what the last pass's histogram suggests for the next one
-  int chem_sample = 0;              // ceiling the opening sample ran under (0: no sample in this pass)
-  int chem_list0_done = 0;          // entries of deferred list 0 the opening sample has already restarted
   int *d_defer[2] = {nullptr, nullptr}; // cells dropped by a tier of the heating global pass (ping-pong lists)
   int *d_chemctl = nullptr;         // {count of list 0, count of list 1, histogram[CHEM_HIST]}
   // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
@@ -2163,6 +2189,7 @@ static StepScalars scalars(c2r_ctx *c) {
   s.cd.zred = c->zred;
   s.cd.H0 = c->H0;
   s.cd.Omega0 = c->Omega0;
+  s.cd.logtab = nullptr;
   return s;
 }
 
@@ -3109,50 +3136,48 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
 // The global pass over a range of cells, queued behind `after_event` (an event of another stream, e.g. the
 // one on which the caller's sum over ranks of these cells completes; may be null).  A range starting at
 // cell 0 opens a pass (zeroes the non-converged count); c2r_global_pass_finish closes it.
-// Heating global pass in tiers.  The number of sub-steps thermal() takes spans four orders of magnitude (cells at
-// an ionisation front sub-cycle the energy equation hundreds to thousands of times next to neighbours that
-// need two), and a wave lasts as long as its slowest lane: measured on a 1024-source heating run, 90 % of the
-// lane-time of a plain launch was idle.  So the first launch of a pass gives every cell `chem_b1` sub-steps;
-// the cells that need more are dropped and redone, densely packed, by follow-up launches with ceilings 8 and
-// 64 times higher and finally without one.  The ceiling is twice the 90th percentile of the histogram of
-// sub-steps per cell -- of the previous pass, or, when that one had no tail, of a sample this pass opens with --
-// or 0 (no ceiling) when there is no tail to cut.
+// Heating global pass in tiers.  The number of sub-steps thermal() takes for a cell spans four orders of magnitude
+// (cells at an ionisation front sub-cycle the energy equation hundreds to thousands of times, over hundreds of
+// do_chemistry iterations, next to neighbours that need two), a wave lasts as long as its slowest lane, and a sub-step
+// is a chain of dependent operations some 2 700 cycles long (the log10 of coolin, ten cooling-curve look-ups, six
+// divisions) with two waves per SIMD to hide it: a plain launch leaves nine tenths of the lane-time idle.  So every
+// launch gives its cells a ceiling of sub-steps; a cell that needs more stores nothing, is put on a list and is redone
+// from scratch, densely packed with its likes, by the next launch under a ceiling four times higher: 16, 64, 256,
+// 1 024, then none.  Within a tier the cells then differ by a factor of four at most, and what the dropped cells did
+// in vain is a third of their useful work at worst.  (Beyond 1 024 a launch holds a few hundred waves, all resident at
+// once, and lasts as long as its longest chain whatever the others do: further rungs only add their own chains.)  (Rounds 1 and 2 chose ONE first ceiling from
+// the previous pass's histogram, twice its 90th percentile, and went on in steps of eight: measured on the 128 faint
+// sources of a configs[3] rank with heating, C2R_CHEM_LOG, that first launch took 90-100 ms of a 125 ms pass under a
+// ceiling of 512 while two thirds of its cells needed fewer than 64 sub-steps.)  The last tier is the longest chain
+// of the mesh -- some 14 000 sub-steps, 16 ms, however few cells are left -- and nothing on the device shortens that.
 // Results do not depend on any of this: a dropped cell stores nothing and is recomputed from the same inputs.
-// (Cells that run into the 400-iteration cap of do_chemistry with few sub-steps stay in the first launch:
-// each is one long serial chain, and the earlier it starts the better.)
-constexpr int CHEM_HIST = 24;
-
-// first ceiling from a histogram of sub-steps per cell (bucket b: counts in [2^(b-1), 2^b)): twice the 90th
-// percentile if the 99.9th lies at least 8 times above it, otherwise none
-static int chemistry_ceiling(const int *hist) {
-  long long total = 0, acc = 0;
-  for (int b = 0; b < CHEM_HIST; b++) total += hist[b];
-  int b90 = 0, b999 = 0;
-  for (int b = 0; b < CHEM_HIST; b++) {
-    acc += hist[b];
-    if (acc * 10 < total * 9) b90 = b + 1;
-    if (acc * 1000 < total * 999) b999 = b + 1;
-  }
-  return (total > 0 && b999 >= b90 + 3) ? std::max(16, 1 << std::min(b90 + 1, 20)) : 0;
-}
+constexpr int CHEM_FIRST_CEILING = 16, CHEM_CEILING_STEP = 4, CHEM_TIERS = 5;
 
 static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first, size_t count, const int *list, int budget,
-                            int *deferred, int *ndeferred, int part = 0) {
+                            int *deferred, int *ndeferred) {
   if (count == 0) return 0;
   const Grid g = c->g;
   const StepScalars sc = scalars(c);
-  int nblk = (int)((count + C2R_CHEM_BLOCK - 1) / C2R_CHEM_BLOCK);
-  if (part == 1) nblk = (nblk + 63) / 64;
+  // C2R_CHEM_LDS=0 (diagnostic): tables from global memory in every tier
+  static const bool lds_tiers = !(getenv("C2R_CHEM_LDS") && atoi(getenv("C2R_CHEM_LDS")) == 0);
+  const bool lds = !c->isothermal && list != nullptr && lds_tiers; // the repacked tiers of a heating pass
+  const int bs = lds ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK;
+  const int nblk = (int)((count + bs - 1) / bs);
   if (c->isothermal)
-    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
+    hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, 0,
-                       (int *)nullptr, (int *)nullptr, (int *)nullptr, 0, c->d_stateT);
-  else
-    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(C2R_CHEM_BLOCK), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
+                       (int *)nullptr, (int *)nullptr, (int *)nullptr, c->d_stateT);
+  else if (lds)
+    hipLaunchKernelGGL((k_chemistry<true, true>), dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_chemctl + 2, part, c->d_stateT);
+                       ndeferred, c->d_chemctl + 2, c->d_stateT);
+  else
+    hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
+                       ndeferred, c->d_chemctl + 2, c->d_stateT);
   HIPCHK(c, hipGetLastError());
   c->tm.chem_launches++;
   return 0;
@@ -3161,8 +3186,8 @@ static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first,
 static int ensure_chemistry_buffers(c2r_ctx *c) {
   if (!c->isothermal && !c->d_defer[0]) {
     for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
-    HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (2 + CHEM_HIST))); // two list counts, then the histogram
-    HIPCHK(c, hipMemset(c->d_chemctl, 0, sizeof(int) * (2 + CHEM_HIST)));
+    HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST))); // two list counts, then the histogram
+    HIPCHK(c, hipMemset(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST)));
   }
   return 0;
 }
@@ -3263,7 +3288,7 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
   if (ensure_chemistry_buffers(c)) return 1;
   if (first_cell == 0) {
     HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
-    if (heat) HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (2 + CHEM_HIST), c->stream));
+    if (heat) HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST), c->stream));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     // the second stream takes every other piece: it must see the zeroed counters (and everything before)
     HIPCHK(c, hipEventRecord(c->ev_sweep_done[0], c->stream));
@@ -3279,36 +3304,7 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
   // the next piece fills the chip while the previous one drains.
   hipStream_t st = (c->chem_pieces++ & 1) ? c->stream2 : c->stream;
   if (after_event) HIPCHK(c, hipStreamWaitEvent(st, static_cast<hipEvent_t>(after_event), 0));
-  if (heat && first_cell == 0) {
-    // ceiling of this pass: what the previous pass's histogram suggests; if that is "none" (nothing known yet,
-    // or the previous pass had no tail -- the first iteration of a time step typically has none and the second
-    // a heavy one), a sample decides: every 64th wave of this piece, itself under a ceiling so that it returns
-    // within a millisecond
-    c->chem_b1 = c->chem_b1_next;
-    if (c->chem_b1 == 0 && ncells >= (size_t)64 * 64 * C2R_CHEM_BLOCK) {
-      int ctl[2 + CHEM_HIST]; // the two list counts, then the histogram (the layout of d_chemctl)
-      c->chem_sample = 512;
-      if (launch_chemistry(c, st, dt, first_cell, ncells, nullptr, c->chem_sample, c->d_defer[0], c->d_chemctl, 1)) return 1;
-      HIPCHK(c, hipMemcpyAsync(ctl, c->d_chemctl, sizeof ctl, hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipStreamSynchronize(st));
-      const int dropped = ctl[0];
-      // cells the sample dropped count as "above 512"
-      int h2[CHEM_HIST];
-      for (int b = 0; b < CHEM_HIST; b++) h2[b] = ctl[2 + b];
-      h2[11] += dropped;
-      c->chem_b1 = chemistry_ceiling(h2);
-      // the few cells the sample dropped are long chains: they restart at once, without ceiling, beside the bulk
-      c->chem_list0_done = dropped;
-      if (dropped > 0) {
-        hipStream_t other = st == c->stream ? c->stream2 : c->stream;
-        HIPCHK(c, hipEventRecord(c->ev_fork, st));
-        HIPCHK(c, hipStreamWaitEvent(other, c->ev_fork, 0));
-        if (launch_chemistry(c, other, dt, 0, (size_t)dropped, c->d_defer[0], 0, c->d_defer[1], c->d_chemctl + 1)) return 1;
-      }
-      return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, c->chem_b1, c->d_defer[0], c->d_chemctl, 2);
-    }
-  }
-  return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, heat ? c->chem_b1 : 0, c->d_defer[0], c->d_chemctl);
+  return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, heat ? CHEM_FIRST_CEILING : 0, c->d_defer[0], c->d_chemctl);
 }
 
 extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
@@ -3319,30 +3315,39 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rates_done[0], 0));
   if (!c->isothermal) {
     // later tiers: the cells dropped by the previous launch(es), densely packed
+    // C2R_CHEM_LOG=1 (diagnostic): where the time of a heating pass goes, tier by tier, on stderr
+    static const bool chem_log = getenv("C2R_CHEM_LOG") && atoi(getenv("C2R_CHEM_LOG")) > 0;
+    auto t_tier = std::chrono::steady_clock::now();
     int cur = 0;
-    long long ceiling = c->chem_b1;
-    size_t done = (size_t)c->chem_list0_done; // head of list 0 already restarted by the opening sample
-    for (int t = 1; t <= 3 && ceiling > 0; t++) {
+    long long ceiling = CHEM_FIRST_CEILING;
+    for (int t = 1; t < CHEM_TIERS; t++) {
       int n = 0;
       HIPCHK(c, hipMemcpyAsync(&n, c->d_chemctl + cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      if ((size_t)n <= done) break;
+      if (chem_log) {
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "c2ray_hip: heating pass, tier %d (ceiling %lld sub-steps) done after %.1f ms: %d cells deferred\n", t - 1,
+                ceiling, std::chrono::duration<double, std::milli>(now - t_tier).count(), n);
+        t_tier = now;
+      }
+      if (n <= 0) break;
       const int nxt = cur ^ 1;
-      ceiling *= 8;
+      ceiling *= CHEM_CEILING_STEP;
       HIPCHK(c, hipMemsetAsync(c->d_chemctl + nxt, 0, sizeof(int), c->stream));
-      if (launch_chemistry(c, c->stream, c->chem_dt, done, (size_t)n - done, c->d_defer[cur], t == 3 ? 0 : (int)ceiling,
+      if (launch_chemistry(c, c->stream, c->chem_dt, 0, (size_t)n, c->d_defer[cur], t == CHEM_TIERS - 1 ? 0 : (int)ceiling,
                            c->d_defer[nxt], c->d_chemctl + nxt))
         return 1;
       cur = nxt;
-      done = 0;
     }
-    c->chem_sample = 0;
-    c->chem_list0_done = 0;
-    // the whole pass's histogram is the first guess for the next pass
-    int hist[CHEM_HIST];
-    HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->chem_b1_next = chemistry_ceiling(hist);
+    if (chem_log) {
+      int hist[CHEM_HIST + 2];
+      HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      fprintf(stderr, "c2ray_hip: heating pass, last tier done after %.1f ms; longest chain: %d thermal sub-steps, %d do_chemistry iterations; cells per power of two of sub-steps:",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tier).count(), hist[CHEM_HIST], hist[CHEM_HIST + 1]);
+      for (int b = 0; b < CHEM_HIST; b++) fprintf(stderr, " %d", hist[b]);
+      fprintf(stderr, "\n");
+    }
   }
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   if (c->want_iter_stats) {

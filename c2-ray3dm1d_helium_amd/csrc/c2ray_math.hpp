@@ -293,6 +293,12 @@ C2R_MHD double log10_norm(double x, const double *tab) {
 }
 C2R_MHD const double *log_table() { return GMT(log_tab); }
 C2R_MHD double log10_norm(double x) { return log10_norm(x, GMT(log_tab)); }
+// the same with the (invc, logc) table wherever the caller keeps it (LDS)
+C2R_MHD double log10_pos(double x, const double *tab) {
+  const uint32_t hi = (uint32_t)(asuint64(x) >> 32);
+  if (hi - 0x00100000u >= 0x7FE00000u) return log10_(x); // zero, subnormal, negative, inf, nan
+  return log10_norm(x, tab);
+}
 C2R_MHD double log10_pos(double x) {
   const uint32_t hi = (uint32_t)(asuint64(x) >> 32);
   if (hi - 0x00100000u >= 0x7FE00000u) return log10_(x); // zero, subnormal, negative, inf, nan
@@ -438,5 +444,6 @@ C2R_MHD double pow_(double x, double y) {
 #define C2R_MATH_EXP(x) ::c2r::gm::exp_(x)
 #define C2R_MATH_LOG10(x) ::c2r::gm::log10_(x)
 #define C2R_MATH_LOG10P(x) ::c2r::gm::log10_pos(x)
+#define C2R_MATH_LOG10PT(x, tab) ::c2r::gm::log10_pos(x, tab)
 #define C2R_MATH_LOG10N(x) ::c2r::gm::log10_norm(x)
 #define C2R_MATH_POW(x, y) ::c2r::gm::pow_(x, y)

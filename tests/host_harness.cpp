@@ -156,7 +156,7 @@ void hh_thermal(double dt, double *tend, double *tavg, double de, double nd, con
                 double zred, double H0, double Omega0) {
   IonStates ion;
   std::memcpy(&ion, ion15, sizeof ion);
-  CoolData cd{T.cool.data(), T.mintemp, T.dtemp, zred, H0, Omega0};
+  CoolData cd{T.cool.data(), T.mintemp, T.dtemp, zred, H0, Omega0, nullptr};
   thermal(cd, dt, *tend, *tavg, de, nd, ion, heat);
 }
 
