@@ -3143,15 +3143,18 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
 // divisions) with two waves per SIMD to hide it: a plain launch leaves nine tenths of the lane-time idle.  So every
 // launch gives its cells a ceiling of sub-steps; a cell that needs more stores nothing, is put on a list and is redone
 // from scratch, densely packed with its likes, by the next launch under a ceiling four times higher: 16, 64, 256,
-// 1 024, then none.  Within a tier the cells then differ by a factor of four at most, and what the dropped cells did
-// in vain is a third of their useful work at worst.  (Beyond 1 024 a launch holds a few hundred waves, all resident at
-// once, and lasts as long as its longest chain whatever the others do: further rungs only add their own chains.)  (Rounds 1 and 2 chose ONE first ceiling from
+// 1 024, then none -- and none earlier once the cells that are left fit the device all at once (two waves per SIMD:
+// 131 072 cells): such a launch lasts as long as its longest chain whatever the others do.  Within a tier the cells
+// then differ by a factor of four at most, and what the dropped cells did in vain is a third of their useful work
+// at worst.  (Rungs at 4 096 and 16 384 were measured too: 1-2 ms slower at 256^3, where they only add their own
+// chains, and 0.5-1 s slower on 512^3 with 10^4 sources, where two thirds of the cells beyond 1 024 lie beyond 4 096
+// as well and do 4 096 sub-steps in vain.)  (Rounds 1 and 2 chose ONE first ceiling from
 // the previous pass's histogram, twice its 90th percentile, and went on in steps of eight: measured on the 128 faint
 // sources of a configs[3] rank with heating, C2R_CHEM_LOG, that first launch took 90-100 ms of a 125 ms pass under a
 // ceiling of 512 while two thirds of its cells needed fewer than 64 sub-steps.)  The last tier is the longest chain
 // of the mesh -- some 14 000 sub-steps, 16 ms, however few cells are left -- and nothing on the device shortens that.
 // Results do not depend on any of this: a dropped cell stores nothing and is recomputed from the same inputs.
-constexpr int CHEM_FIRST_CEILING = 16, CHEM_CEILING_STEP = 4, CHEM_TIERS = 5;
+constexpr int CHEM_FIRST_CEILING = 16, CHEM_CEILING_STEP = 4, CHEM_TIERS = 5, CHEM_RESIDENT_CELLS = 131072;
 
 static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first, size_t count, const int *list, int budget,
                             int *deferred, int *ndeferred) {
@@ -3334,10 +3337,12 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
       const int nxt = cur ^ 1;
       ceiling *= CHEM_CEILING_STEP;
       HIPCHK(c, hipMemsetAsync(c->d_chemctl + nxt, 0, sizeof(int), c->stream));
-      if (launch_chemistry(c, c->stream, c->chem_dt, 0, (size_t)n, c->d_defer[cur], t == CHEM_TIERS - 1 ? 0 : (int)ceiling,
-                           c->d_defer[nxt], c->d_chemctl + nxt))
+      const bool last = t == CHEM_TIERS - 1 || n <= CHEM_RESIDENT_CELLS;
+      if (launch_chemistry(c, c->stream, c->chem_dt, 0, (size_t)n, c->d_defer[cur], last ? 0 : (int)ceiling, c->d_defer[nxt],
+                           c->d_chemctl + nxt))
         return 1;
       cur = nxt;
+      if (last) break;
     }
     if (chem_log) {
       int hist[CHEM_HIST + 2];
