@@ -67,6 +67,39 @@ def test_two_ranks_on_one_gpu(pkg, gold):
     assert res["niter"] == plain["niter"] and res["nbox"] == plain["nbox"] and res["loss"] == plain["loss"]
     for k in ("xh", "temp", "phih"):
         assert np.array_equal(res[k], plain[k]), k
+    # ... and against the ORACLE run with this very association of the sum over sources: rank 0 adds up sources 1
+    # and 3, rank 1 has source 2, the sum over the ranks is (s1 + s3) + s2 -- not the serial (s1 + s2) + s3 of the
+    # reference's one-rank run, which is why the comparison with the reference's own numbers below is to rounding.
+    # Same iteration count, every grid bit for bit.
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as orc
+    from oracle_engine import OracleEngine
+    from test_host_logic import _inputs
+    with np.load(pkg.evolve.DEFAULT_TABLES) as t:
+        T = orc.Tables({k: t[k] for k in t.files})
+
+    class TwoRanksInOne:
+        rank, size = 0, 2   # size 2: the step-wise loop of the Python host
+
+        def pass_and_allreduce(self, e, nslab=8):
+            parts = []
+            for r in range(2):
+                e.set_rates_to_zero()
+                e.pass_sources(1 + r, 2)
+                parts.append((e.s.phih.copy(), e.s.phihe.copy(), e.s.phiheat.copy(), e.loss, e.nbox))
+            a, b = parts
+            e.s.phih[:], e.s.phihe[:], e.s.phiheat[:] = a[0] + b[0], a[1] + b[1], a[2] + b[2]
+            e.loss, e.nbox = a[3] + b[3], a[4] + b[4]
+
+    i, _, mesh, mat, grid, src, cosmo = _inputs(pkg, gold, "tap_N16_heat_3src.npz", 2)
+    ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), engine=OracleEngine(mesh, T), comm=TwoRanksInOne())
+    n_orc = ev.evolve3D(0.0, float(i["dt"][0]), 0, mat, grid, src, cosmo)
+    assert res["niter"] == n_orc
+    assert np.array_equal(res["xh"], mat.xh)
+    assert np.array_equal(res["temp"], mat.temperature_grid)
+    assert np.array_equal(res["phih"], ev.rates["phih_grid"])
+    assert res["nbox"] == ev.sum_nbox_all
+    assert abs(res["loss"] / ev.photon_loss_all[0] - 1) < 1e-13   # a source's loss is summed in block order on the device
     n = 16 ** 3
     assert abs(res["niter"] - len(o["conv_flags"])) <= 2
     assert res["nbox"] == int(o["sum_nbox_all"][0])
