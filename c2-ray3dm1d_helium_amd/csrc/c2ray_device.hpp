@@ -492,12 +492,15 @@ C2R_HD TauPos tau_table_position(double tau, const double *logtab = C2R_LOGTAB_D
 // Two optical depths at once (the two faces of a cell): both table-path evaluations of the log run as one
 // straight line -- their loads and dependent fma chains overlap --, and the polynomial path of __log_fma
 // (arguments near 1: one in ten, spatially coherent) is entered only when some lane of the wave needs it.
-// `logtab4`, when given, is the table with the power of two folded in (gm::LogEntry; k_rates keeps it in LDS).
-C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab, TauPos &pa, TauPos &pb,
-                                const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
+// The table comes in two forms, told apart by its type: (invc, logc) pairs (const double *) or the 256 entries with
+// the power of two folded in (const gm::LogEntry *; k_rates keeps that one in LDS).
+C2R_HD double log_table_path_of(const gm::Log10Arg &a, const double *tab, const gm::LogPins *pins) { return gm::log_table_path(a, tab, pins); }
+C2R_HD double log_table_path_of(const gm::Log10Arg &a, const gm::LogEntry *tab, const gm::LogPins *pins) { return gm::log_table_path4(a, tab, pins); }
+template <class LT>
+C2R_HD void tau_table_positions(double tau_a, double tau_b, const LT *logtab, TauPos &pa, TauPos &pb,
+                                const gm::LogPins *pins = nullptr) {
   const gm::Log10Arg a = gm::log10_split(dmax_const(tau_a, 1.0e-20)), b = gm::log10_split(dmax_const(tau_b, 1.0e-20));
-  double lga = logtab4 ? gm::log_table_path4(a, logtab4, pins) : gm::log_table_path(a, logtab, pins);
-  double lgb = logtab4 ? gm::log_table_path4(b, logtab4, pins) : gm::log_table_path(b, logtab, pins);
+  double lga = log_table_path_of(a, logtab, pins), lgb = log_table_path_of(b, logtab, pins);
   const bool na = gm::log10_near1(a), nb = gm::log10_near1(b);
   C2R_COUNT_LANES(12, na || nb);
   C2R_COUNT_LANES(15, na && nb);
@@ -513,8 +516,8 @@ C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *logtab
 C2R_HD TauPos tau_table_position(double tau, const double * = nullptr) {
   return table_position_of_log(C2R_MATH_LOG10N(dmax(1.0e-20, tau)));
 }
-C2R_HD void tau_table_positions(double tau_a, double tau_b, const double *, TauPos &pa, TauPos &pb, const void * = nullptr,
-                                const void * = nullptr) {
+template <class LT>
+C2R_HD void tau_table_positions(double tau_a, double tau_b, const LT *, TauPos &pa, TauPos &pb, const void * = nullptr) {
   pa = tau_table_position(tau_a);
   pb = tau_table_position(tau_b);
 }
@@ -575,7 +578,6 @@ struct CellSrc {
   Recip rvol;      // the shell volume vol_ph as divisor
   bool recip_safe; // the sums of scale_int2/3 lie where recip_nr is exact (see there)
   const gm::LogPins *pins; // see gm::LogPins; may be null
-  const gm::LogEntry *logtab4; // see tau_table_positions; may be null
 };
 
 // RN(1/x) for the denominators of scale_int2 / scale_int3: the instruction sequence the compiler emits for 1.0/x
@@ -640,9 +642,9 @@ struct SedSums {
 // `look_for_zero`: test whether the band is beyond the last non-zero table entry (band_tau_zero); returns
 // whether it was.  Within a class the optical depth falls from band to band, so once no lane of a wave has
 // found a band dead the caller stops asking (a missed skip costs time, never a bit).
-template <bool HEAT, int CLS>
+template <bool HEAT, int CLS, class LT>
 C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
-                       const double *heat_thin, const double *logtab, const double *tau_zero, bool look_for_zero, int b,
+                       const double *heat_thin, const LT *logtab, const double *tau_zero, bool look_for_zero, int b,
                        const CellSrc &c, const Ricotti &ric, SedSums &o) {
   const double NFlux = c.NFlux;
   const double sHI = bd.sigma_HI[b];
@@ -670,7 +672,7 @@ C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const doub
   // both positions always: an optically thin band (no use for pout) is rare, and one straight line for the
   // two logs is worth more than skipping one of them now and then
   TauPos pin, pout;
-  tau_table_positions(tau_in, tau_out, logtab, pin, pout, c.pins, c.logtab4);
+  tau_table_positions(tau_in, tau_out, logtab, pin, pout, c.pins);
 
   // species split of this band (scale_int2 / scale_int3)
   double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
@@ -820,12 +822,12 @@ struct SedAcc {
 // heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands
 // [blo, bhi) (0-based), in three stretches by band class; every sum runs in band order as in the reference.
 // HEAT selects the non-isothermal path.  `logtab`: see tau_table_position.
-template <bool HEAT>
+template <bool HEAT, class LT>
 C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                       const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
                       double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                      double NFlux, const Ricotti &ric, SedAcc &out, const double *logtab, const double *tau_zero,
-                      const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
+                      double NFlux, const Ricotti &ric, SedAcc &out, const LT *logtab, const double *tau_zero,
+                      const gm::LogPins *pins = nullptr) {
   out.photo_HI = out.photo_HeI = out.photo_HeII = 0.0;
   out.photo_out = 0.0;
   out.f_heat = out.f_ion_HI = out.f_ion_HeI = 0.0;
@@ -839,26 +841,25 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
   c.NFlux = NFlux;
   c.rvol = make_recip(vol);
   c.pins = pins;
-  c.logtab4 = logtab4;
   c.recip_safe = column_in_recip_range(c.cell_HI) && column_in_recip_range(c.cell_HeI) && column_in_recip_range(c.cell_HeII);
   SedSums o = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const int e0 = bhi < NB1 ? bhi : NB1, e1 = bhi < NB1 + NB2 ? bhi : NB1 + NB2;
   int b = blo;
   bool look = true;
   for (; b < e0; b++) {
-    const bool dead = band_rates<HEAT, 0>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
+    const bool dead = band_rates<HEAT, 0, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
     C2R_COUNT_LANES(0, !dead);
     look = any_lane(dead);
   }
   look = true;
   for (; b < e1; b++) {
-    const bool dead = band_rates<HEAT, 1>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
+    const bool dead = band_rates<HEAT, 1, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
     C2R_COUNT_LANES(0, !dead);
     look = any_lane(dead);
   }
   look = true;
   for (; b < bhi; b++) {
-    const bool dead = band_rates<HEAT, 2>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
+    const bool dead = band_rates<HEAT, 2, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, ric, o);
     C2R_COUNT_LANES(0, !dead);
     look = any_lane(dead);
   }
@@ -875,15 +876,15 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
 
 
 // photoion_rates for a source with the black-body SED only
-template <bool HEAT>
+template <bool HEAT, class LT = double>
 C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                            const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
                            double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                           double NFlux, const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT,
-                           const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
+                           double NFlux, const Ricotti &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
+                           const gm::LogPins *pins = nullptr) {
   SedAcc a;
-  sed_rates<HEAT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
-                  cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab, bd.tau_zero[0], pins, logtab4);
+  sed_rates<HEAT, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
+                      cin_HeII, cout_HeII, vol, NFlux, ric, a, logtab, bd.tau_zero[0], pins);
   o.photo_HI = a.photo_HI;
   o.photo_HeI = a.photo_HeI;
   o.photo_HeII = a.photo_HeII;
@@ -908,11 +909,11 @@ struct SedSet {
   int lo[NSED], hi[NSED]; // 0-based first band, one past the last band; lo == hi: SED absent
 };
 
-template <bool HEAT>
+template <bool HEAT, class LT = double>
 C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                                  double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
-                                 const Ricotti &ric, PhotoOut &o, const double *logtab = C2R_LOGTAB_DEFAULT,
-                                 const gm::LogPins *pins = nullptr, const gm::LogEntry *logtab4 = nullptr) {
+                                 const Ricotti &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
+                                 const gm::LogPins *pins = nullptr) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
@@ -924,8 +925,8 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
   for (int s = 0; s < NSED; s++) {
     act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
     if (act[s])
-      sed_rates<HEAT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
-                      cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s], pins, logtab4);
+      sed_rates<HEAT, LT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
+                          cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s], pins);
   }
   // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
   for (int s = 0; s < NSED; s++) {

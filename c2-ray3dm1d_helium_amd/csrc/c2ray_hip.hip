@@ -684,15 +684,13 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   // near it.  Without lists every cell walks all nsrc sources of the batch (few sources, boxes that fill the mesh).
   // the (invc, logc) table of the bit-exact log (2 KB) in LDS: two gathers per band iteration that no longer
   // queue behind the photo-table gathers in the vector memory path
+#ifndef C2R_NO_LOGTAB4
+  // ... with the log's power of two folded in (gm::LogEntry, 8 KB)
+  __shared__ gm::LogEntry s_logtab[256];
+  s_logtab[threadIdx.x] = gm::make_log_entry((int)threadIdx.x);
+#else
   __shared__ double s_logtab[256];
   s_logtab[threadIdx.x] = gm::log_table()[threadIdx.x];
-  // the same with the log's power of two folded in (gm::LogEntry, 8 KB): what the band loop reads
-#ifndef C2R_NO_LOGTAB4
-  __shared__ gm::LogEntry s_logtab4_[256];
-  s_logtab4_[threadIdx.x] = gm::make_log_entry((int)threadIdx.x);
-  const gm::LogEntry *s_logtab4 = s_logtab4_;
-#else
-  const gm::LogEntry *s_logtab4 = nullptr;
 #endif
   __syncthreads();
   // two polynomial constants of the log held in vector registers for the whole kernel (gm::LogPins): -0.25 ms per
@@ -782,10 +780,10 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
         PhotoOut o;
         if (MULTI) {
           const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-          photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, s_logtab, pins, s_logtab4);
+          photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, &s_logtab[0], pins);
         } else {
           photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
-                               cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, s_logtab, pins, s_logtab4);
+                               cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, &s_logtab[0], pins);
         }
         a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
         a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);

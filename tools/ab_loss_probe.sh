@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "benchmark_size or config3 or config4 or full_evolve3d or one_iteration" > gpurun_out/ab_tests.log 2>&1 || true
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "benchmark_size or config4 or full_evolve3d or one_iteration" > gpurun_out/ab_tests.log 2>&1 || true
 tail -3 gpurun_out/ab_tests.log
 run() { name=$1; shift; env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err; python - <<PY
 import json
