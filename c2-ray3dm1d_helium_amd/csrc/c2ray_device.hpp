@@ -493,9 +493,12 @@ C2R_HD TauPos tau_table_position(double tau, const double *logtab = C2R_LOGTAB_D
 // straight line -- their loads and dependent fma chains overlap --, and the polynomial path of __log_fma
 // (arguments near 1: one in ten, spatially coherent) is entered only when some lane of the wave needs it.
 // The table comes in two forms, told apart by its type: (invc, logc) pairs (const double *) or the 256 entries with
-// the power of two folded in (const gm::LogEntry *; k_rates keeps that one in LDS).
+// the power of two folded in (const gm::LogEntry *; k_rates keeps that one in LDS).  (A third, with log10's two
+// products of its own power of two tabulated per exponent as well -- 17 KB more LDS, three instructions fewer per
+// logarithm -- was measured: 19.4 against 18.2 ms per launch; six more live registers cost the fifth wave per SIMD.)
 C2R_HD double log_table_path_of(const gm::Log10Arg &a, const double *tab, const gm::LogPins *pins) { return gm::log_table_path(a, tab, pins); }
 C2R_HD double log_table_path_of(const gm::Log10Arg &a, const gm::LogEntry *tab, const gm::LogPins *pins) { return gm::log_table_path4(a, tab, pins); }
+
 template <class LT>
 C2R_HD void tau_table_positions(double tau_a, double tau_b, const LT *logtab, TauPos &pa, TauPos &pb,
                                 const gm::LogPins *pins = nullptr) {

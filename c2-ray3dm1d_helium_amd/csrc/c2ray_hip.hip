@@ -684,7 +684,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   // near it.  Without lists every cell walks all nsrc sources of the batch (few sources, boxes that fill the mesh).
   // the (invc, logc) table of the bit-exact log (2 KB) in LDS: two gathers per band iteration that no longer
   // queue behind the photo-table gathers in the vector memory path
-#ifndef C2R_NO_LOGTAB4
+#if !defined(C2R_NO_LOGTAB4)
   // ... with the log's power of two folded in (gm::LogEntry, 8 KB)
   __shared__ gm::LogEntry s_logtab[256];
   s_logtab[threadIdx.x] = gm::make_log_entry((int)threadIdx.x);
