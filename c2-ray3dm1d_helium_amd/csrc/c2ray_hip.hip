@@ -800,14 +800,17 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     // the one that is kept: leave it in the cell's N_in(HI) slot, which nobody reads any more, for k_loss_stored.
     // Only the shells of the final round count; the others were done -- and counted, for a loss that is not kept
     // -- in earlier rounds.
+    // (Isothermal kernels only: the heating kernels, three times the code and short of registers as they are, lose
+    // 10 % of their launch to the second copy -- 34.0 against 31.2 ms -- where the isothermal one gains; heating runs
+    // evaluate the kept loss with k_loss beside the rates launch, as rounds 1 and 2 did.)
     bool surface = false;
-    if (S.loss_lo >= 0) { // uniform
+    if (!HEAT && S.loss_lo >= 0) { // uniform
       const int ia = di < 0 ? -di : di, ja = dj < 0 ? -dj : dj, ka = dk < 0 ? -dk : dk;
       const int shell = ia > ja ? (ia > ka ? ia : ka) : (ja > ka ? ja : ka);
       surface = (di == S.lo[0] || dj == S.lo[1] || dk == S.lo[2] || di == S.hi[0] || dj == S.hi[1] || dk == S.hi[2]) &&
                 shell >= S.loss_lo;
     }
-    if (__any(surface ? 1 : 0)) {
+    if (!HEAT && __any(surface ? 1 : 0)) {
       const double photo_out = rates_of_source(std::true_type{});
       if (surface) cs[col_in(p, 0, cz)] = photo_out * sc.vol / vol_ph;
     } else {
@@ -825,6 +828,13 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
 // ---------------------------------------------------------------------------------------------
 // evolve0D_global + do_chemistry (files_for_3D/evolve_point.F90:325-440, :444-646), one cell per lane.
 constexpr int CHEM_HIST = 24; // buckets of the histogram of thermal sub-steps per cell (powers of two)
+// The counters of a pass -- cells not converged, the histogram, the two longest chains -- are one atomic per wave each,
+// and atomics of device scope on ONE address are served one after the other, some 6 ns apiece: with the 262 144
+// single-wave blocks of 256^3 every such counter cost 1.6 ms of a 5 ms heating launch (measured: 6.7 ms with three of
+// them, 5.1 with two, 3.6 with none).  So the waves spread them over CHEM_CTL_COPIES copies, a page apart, chosen by
+// block index; k_chem_ctl_reduce folds the copies into the counters the host reads when the pass is over.
+constexpr int CHEM_CTL_COPIES = 64, CHEM_CTL_STRIDE = 1024;            // copies; ints between two of them
+constexpr int CHEM_CTL_MAXWORK = CHEM_HIST, CHEM_CTL_MAXNIT = CHEM_HIST + 1, CHEM_CTL_NOTCONV = CHEM_HIST + 2, CHEM_CTL_SLOTS = CHEM_HIST + 3;
 #ifndef C2R_CHEM_BLOCK
 #define C2R_CHEM_BLOCK 64
 #endif
@@ -843,15 +853,16 @@ __global__ void __launch_bounds__(LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK, C2R_
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
             const double *__restrict__ xhe, double *__restrict__ xh_av, double *__restrict__ xhe_av,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
-            const double *__restrict__ rates, int *__restrict__ conv_flag, double *__restrict__ rc_last,
+            const double *__restrict__ rates, int *__restrict__ ctl, double *__restrict__ rc_last,
             const float *__restrict__ clumping_grid, size_t q_first, size_t q_end, const int *__restrict__ list,
-            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, int *__restrict__ hist,
-            double *__restrict__ packed) {
+            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, double *__restrict__ packed) {
   // Cells are taken from the range [q_first, q_end) or, when `list` is given, from list[q_first .. q_end).
-  // Heating runs (hist != null): budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps --
-  // nothing of it is stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds
-  // only such cells (c2r_global_pass_finish).  hist counts the cells per power of two of sub-steps.
+  // Heating runs: budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps -- nothing of it is
+  // stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds only such cells
+  // (c2r_global_pass_finish).  ctl: the spread counters (see CHEM_CTL_COPIES), among them the cells per power of
+  // two of sub-steps.
   const size_t nc = g.ncell;
+  int *const my_ctl = ctl + (size_t)(blockIdx.x & (CHEM_CTL_COPIES - 1)) * CHEM_CTL_STRIDE;
   __shared__ double s_cool[LDSTAB ? 5 * NCOOL : 1];
   __shared__ double s_log[LDSTAB ? 256 : 1];
   if (LDSTAB) {
@@ -860,15 +871,18 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
     __syncthreads();
     sc.cd.cool = s_cool;
     sc.cd.logtab = s_log;
+  } else {
+    sc.cd.logtab = nullptr; // known at compile time: coolin's choice of table folds away
   }
   const size_t idx = q_first + (size_t)blockIdx.x * (LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK) + threadIdx.x;
   int notconv = 0;
   int bucket = -1;
   int work_done = 0, nit_done = 0;
+  bool dropped = false;
+  int q_dropped = 0;
   if (idx < q_end) {
     const size_t q = list ? (size_t)list[idx] : idx;
     int work = 0;
-    bool dropped = false;
     // clumping_point for type_of_clumping = 5 (evolve_point.F90:483-484; REAL(4) grid)
     const double clumping = clumping_grid ? (double)clumping_grid[q] : sc.clumping;
     IonStates ion;
@@ -945,9 +959,9 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
       if (nit > 400) break;
     }
     if (dropped) {
-      deferred[atomicAdd(ndeferred, 1)] = (int)q;
+      q_dropped = (int)q;
     } else {
-    if (HEAT && hist) bucket = work > 0 ? 32 - __clz(work) : 0;
+    if (HEAT) bucket = work > 0 ? 32 - __clz(work) : 0;
     work_done = work;
     nit_done = nit;
     // The reference keeps the coefficients in module-global variables (cgsconstants.f90:106-133): after
@@ -984,33 +998,59 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
     packed[q + 2 * nc] = dmax(ion.he_av[1], epsilon) * ndens_p;
     } // not dropped
   }
-  if (HEAT && hist) {
+  const int lane = threadIdx.x & 63;
+  if (HEAT) {
+    // the dropped cells of the wave take consecutive places in the list: one atomic per wave
+    const unsigned long long dm = __ballot(dropped);
+    if (dm) {
+      const int leader = __ffsll((long long)dm) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(ndeferred, (int)__popcll(dm));
+      base = __shfl(base, leader, 64);
+      if (dropped) deferred[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = q_dropped;
+    }
     // the longest chain of the launch: most thermal sub-steps and most do_chemistry iterations of one cell
-    // (hist[CHEM_HIST], hist[CHEM_HIST + 1]; diagnostics, C2R_CHEM_LOG)
+    // (diagnostics, C2R_CHEM_LOG).  A plain look at the copy first: it only ever grows, so a stale value costs one
+    // atomic too many and never one too few.
     int wmax = bucket >= 0 ? work_done : 0, nmax = bucket >= 0 ? nit_done : 0;
     for (int off = 32; off > 0; off >>= 1) {
       wmax = max(wmax, __shfl_xor(wmax, off, 64));
       nmax = max(nmax, __shfl_xor(nmax, off, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
-      if (wmax > 0) atomicMax(&hist[CHEM_HIST], wmax);
-      if (nmax > 0) atomicMax(&hist[CHEM_HIST + 1], nmax);
+    if (lane == 0) {
+      if (wmax > *(volatile int *)&my_ctl[CHEM_CTL_MAXWORK]) atomicMax(&my_ctl[CHEM_CTL_MAXWORK], wmax);
+      if (nmax > *(volatile int *)&my_ctl[CHEM_CTL_MAXNIT]) atomicMax(&my_ctl[CHEM_CTL_MAXNIT], nmax);
     }
-  }
-  if (HEAT && hist) { // one atomic per wave and distinct bucket
+    // the histogram: one atomic per wave and distinct bucket
     unsigned long long live = __ballot(bucket >= 0);
-    const int lane = threadIdx.x & 63;
     while (live) {
       const int leader = __ffsll((long long)live) - 1;
       const int b = __shfl(bucket, leader, 64);
       const unsigned long long same = __ballot(bucket == b);
-      if (lane == leader) atomicAdd(&hist[b], (int)__popcll(same));
+      if (lane == leader) atomicAdd(&my_ctl[b], (int)__popcll(same));
       live &= ~same;
     }
   }
   // conv_flag = conv_flag + 1 (evolve_point.F90:423): integer count, order-independent
   const unsigned long long m = __ballot(notconv);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(conv_flag, (int)__popcll(m));
+  if (lane == 0 && m) atomicAdd(&my_ctl[CHEM_CTL_NOTCONV], (int)__popcll(m));
+}
+
+// The spread counters of k_chemistry, folded (and zeroed for the next pass): the cells not converged are added to
+// conv_flag, the histogram and the two maxima to hist (heating; null otherwise).
+__global__ void k_chem_ctl_reduce(int *__restrict__ ctl, int *__restrict__ conv_flag, int *__restrict__ hist) {
+  const int t = threadIdx.x;
+  if (t >= CHEM_CTL_SLOTS) return;
+  const bool is_max = t == CHEM_CTL_MAXWORK || t == CHEM_CTL_MAXNIT;
+  int acc = 0;
+  for (int k = 0; k < CHEM_CTL_COPIES; k++) {
+    int *p = ctl + (size_t)k * CHEM_CTL_STRIDE + t;
+    const int v = *p;
+    *p = 0;
+    acc = is_max ? max(acc, v) : acc + v;
+  }
+  if (t == CHEM_CTL_NOTCONV) *conv_flag += acc;
+  else if (hist) hist[t] = is_max ? max(hist[t], acc) : hist[t] + acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1441,6 +1481,7 @@ struct c2r_ctx {
   double *h_stat = nullptr;        // pinned, 8
   double *d_iter = nullptr;        // k_iter_stats: STAT_BLOCKS*(ITER_NV+2) partials + 32 results
   double *h_iter = nullptr;        // pinned, 32
+  int chem_first = 16;              // first rung of the next heating pass's ladder of sub-step ceilings (CHEM_FIRST_CEILING)
   // c2r_evolve0d: the column block of the source being traced cell by cell, and which source that is
   double *d_point_cols = nullptr;
   int point_ns = 0, point_niter = 0;
@@ -1471,6 +1512,7 @@ struct c2r_ctx {
   int chem_pieces = 0;              // pieces of the open global pass (c2r_global_pass_cells)
   double chem_dt = 0.0;
   int *d_defer[2] = {nullptr, nullptr}; // cells dropped by a tier of the heating global pass (ping-pong lists)
+  int *d_chemspread = nullptr;      // the per-wave counters of k_chemistry, CHEM_CTL_COPIES copies (k_chem_ctl_reduce)
   int *d_chemctl = nullptr;         // {count of list 0, count of list 1, histogram[CHEM_HIST]}
   // slab-wise hand-over of the rate grids (c2r_pass_sources_begin / _wait_slab / _end)
   bool pass_open = false;
@@ -1735,7 +1777,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
       if (p) (void)hipFree(p);
   void *ptrs[] = {c->d_photo_thick, c->d_photo_thin, c->d_heat_thick, c->d_heat_thin, c->d_bands, c->d_cool,
                   c->d_ndens, c->d_xh, c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp,
-                  c->d_rates_own, c->d_stateT, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl};
+                  c->d_rates_own, c->d_stateT, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl, c->d_chemspread};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto &list : c->segs)
@@ -2782,7 +2824,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     bool any_final = false;
     // C2R_FINAL_LOSS_KERNEL=1 (diagnostic): evaluate the kept losses of final rounds with k_loss, beside the rates
     // launch, as rounds 1 and 2 of this library did, instead of taking them from the rates launch
-    static const bool legacy_final_loss = getenv("C2R_FINAL_LOSS_KERNEL") && atoi(getenv("C2R_FINAL_LOSS_KERNEL")) > 0;
+    static const bool legacy_env = getenv("C2R_FINAL_LOSS_KERNEL") && atoi(getenv("C2R_FINAL_LOSS_KERNEL")) > 0;
+    const bool legacy_final_loss = legacy_env || !c->isothermal; // heating kernels do not keep photo_out (see k_rates)
     for (int b = 0; b < nb; b++) {
       SrcDev &S = c->h_src[set][b];
       const Box fb = round_box(reach, run[b].nbox);
@@ -3142,7 +3185,9 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
 // launch gives its cells a ceiling of sub-steps; a cell that needs more stores nothing, is put on a list and is redone
 // from scratch, densely packed with its likes, by the next launch under a ceiling four times higher: 16, 64, 256,
 // 1 024, then none -- and none earlier once the cells that are left fit the device all at once (two waves per SIMD:
-// 131 072 cells): such a launch lasts as long as its longest chain whatever the others do.  Within a tier the cells
+// 131 072 cells): such a launch lasts as long as its longest chain whatever the others do.  The ladder starts at the
+// lowest rung under which at least half of the PREVIOUS pass's cells finished (a smoothly ionised box whose cells all
+// need some tens of sub-steps would otherwise do 16 of them in vain for every cell).  Within a tier the cells
 // then differ by a factor of four at most, and what the dropped cells did in vain is a third of their useful work
 // at worst.  (Rungs at 4 096 and 16 384 were measured too: 1-2 ms slower at 256^3, where they only add their own
 // chains, and 0.5-1 s slower on 512^3 with 10^4 sources, where two thirds of the cells beyond 1 024 lie beyond 4 096
@@ -3152,7 +3197,7 @@ extern "C" int c2r_do_source(c2r_ctx *c, int ns) {
 // ceiling of 512 while two thirds of its cells needed fewer than 64 sub-steps.)  The last tier is the longest chain
 // of the mesh -- some 14 000 sub-steps, 16 ms, however few cells are left -- and nothing on the device shortens that.
 // Results do not depend on any of this: a dropped cell stores nothing and is recomputed from the same inputs.
-constexpr int CHEM_FIRST_CEILING = 16, CHEM_CEILING_STEP = 4, CHEM_TIERS = 5, CHEM_RESIDENT_CELLS = 131072;
+constexpr int CHEM_FIRST_CEILING = 16, CHEM_CEILING_STEP = 4, CHEM_LAST_CEILING = 1024, CHEM_TIERS = 6, CHEM_RESIDENT_CELLS = 131072;
 
 static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first, size_t count, const int *list, int budget,
                             int *deferred, int *ndeferred) {
@@ -3166,25 +3211,38 @@ static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first,
   const int nblk = (int)((count + bs - 1) / bs);
   if (c->isothermal)
     hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_chemspread,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, 0,
-                       (int *)nullptr, (int *)nullptr, (int *)nullptr, c->d_stateT);
+                       (int *)nullptr, (int *)nullptr, c->d_stateT);
   else if (lds)
     hipLaunchKernelGGL((k_chemistry<true, true>), dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_chemspread,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_chemctl + 2, c->d_stateT);
+                       ndeferred, c->d_stateT);
   else
     hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
-                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_conv,
+                       c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_chemspread,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_chemctl + 2, c->d_stateT);
+                       ndeferred, c->d_stateT);
   HIPCHK(c, hipGetLastError());
   c->tm.chem_launches++;
   return 0;
 }
 
+// the spread counters of the launches so far, folded into d_conv and (heating) the histogram behind d_chemctl + 2
+static int fold_chemistry_counters(c2r_ctx *c, hipStream_t st) {
+  hipLaunchKernelGGL(k_chem_ctl_reduce, dim3(1), dim3(64), 0, st, c->d_chemspread, c->d_conv,
+                     c->isothermal ? (int *)nullptr : c->d_chemctl + 2);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 static int ensure_chemistry_buffers(c2r_ctx *c) {
+  if (!c->d_chemspread) {
+    const size_t bytes = sizeof(int) * (size_t)CHEM_CTL_COPIES * CHEM_CTL_STRIDE;
+    HIPCHK(c, hipMalloc(&c->d_chemspread, bytes));
+    HIPCHK(c, hipMemset(c->d_chemspread, 0, bytes)); // k_chem_ctl_reduce leaves it zeroed every time
+  }
   if (!c->isothermal && !c->d_defer[0]) {
     for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
     HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST))); // two list counts, then the histogram
@@ -3209,6 +3267,7 @@ extern "C" int c2r_evolve0d_global(c2r_ctx *c, double dt, const int pos[3], int 
   const size_t q = (size_t)(pos[0] - 1) + (size_t)g.n1 * ((size_t)(pos[1] - 1) + (size_t)g.n2 * (size_t)(pos[2] - 1));
   HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
   if (launch_chemistry(c, c->stream, dt, q, 1, nullptr, 0, c->d_defer[0], c->d_chemctl)) return 1;
+  if (fold_chemistry_counters(c, c->stream)) return 1;
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (conv_flag) *conv_flag += *c->h_conv;
@@ -3305,7 +3364,7 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
   // the next piece fills the chip while the previous one drains.
   hipStream_t st = (c->chem_pieces++ & 1) ? c->stream2 : c->stream;
   if (after_event) HIPCHK(c, hipStreamWaitEvent(st, static_cast<hipEvent_t>(after_event), 0));
-  return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, heat ? CHEM_FIRST_CEILING : 0, c->d_defer[0], c->d_chemctl);
+  return launch_chemistry(c, st, dt, first_cell, ncells, nullptr, heat ? c->chem_first : 0, c->d_defer[0], c->d_chemctl);
 }
 
 extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
@@ -3320,7 +3379,7 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     static const bool chem_log = getenv("C2R_CHEM_LOG") && atoi(getenv("C2R_CHEM_LOG")) > 0;
     auto t_tier = std::chrono::steady_clock::now();
     int cur = 0;
-    long long ceiling = CHEM_FIRST_CEILING;
+    long long ceiling = c->chem_first;
     for (int t = 1; t < CHEM_TIERS; t++) {
       int n = 0;
       HIPCHK(c, hipMemcpyAsync(&n, c->d_chemctl + cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -3335,23 +3394,38 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
       const int nxt = cur ^ 1;
       ceiling *= CHEM_CEILING_STEP;
       HIPCHK(c, hipMemsetAsync(c->d_chemctl + nxt, 0, sizeof(int), c->stream));
-      const bool last = t == CHEM_TIERS - 1 || n <= CHEM_RESIDENT_CELLS;
+      const bool last = t == CHEM_TIERS - 1 || n <= CHEM_RESIDENT_CELLS || ceiling > CHEM_LAST_CEILING;
       if (launch_chemistry(c, c->stream, c->chem_dt, 0, (size_t)n, c->d_defer[cur], last ? 0 : (int)ceiling, c->d_defer[nxt],
                            c->d_chemctl + nxt))
         return 1;
       cur = nxt;
       if (last) break;
     }
+    if (fold_chemistry_counters(c, c->stream)) return 1;
+    // where the next pass starts its ladder: the lowest rung under which at least half of this pass's cells finished
+    // (a pass whose cells all need some tens of sub-steps would otherwise do 16 of them in vain for every cell)
+    int hist[CHEM_HIST + 2];
+    HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+      long long total = 0, acc = 0;
+      for (int b = 0; b < CHEM_HIST; b++) total += hist[b];
+      int first = CHEM_FIRST_CEILING, b = 0;
+      for (long long rung = CHEM_FIRST_CEILING; rung <= CHEM_LAST_CEILING; rung *= CHEM_CEILING_STEP) {
+        for (; b < CHEM_HIST && (1LL << b) <= rung; b++) acc += hist[b]; // bucket b holds [2^(b-1), 2^b)
+        first = (int)rung;
+        if (2 * acc >= total) break;
+      }
+      c->chem_first = total > 0 ? first : CHEM_FIRST_CEILING;
+    }
     if (chem_log) {
-      int hist[CHEM_HIST + 2];
-      HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
       fprintf(stderr, "c2ray_hip: heating pass, last tier done after %.1f ms; longest chain: %d thermal sub-steps, %d do_chemistry iterations; cells per power of two of sub-steps:",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tier).count(), hist[CHEM_HIST], hist[CHEM_HIST + 1]);
       for (int b = 0; b < CHEM_HIST; b++) fprintf(stderr, " %d", hist[b]);
       fprintf(stderr, "\n");
     }
   }
+  if (c->isothermal && fold_chemistry_counters(c, c->stream)) return 1;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   if (c->want_iter_stats) {
     // c2r_iteration: the grid reductions the host loop wants after this pass, behind it in the same queue
