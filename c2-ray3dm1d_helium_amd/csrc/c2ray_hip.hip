@@ -1475,6 +1475,7 @@ struct c2r_ctx {
   double *d_colgrid = nullptr;     // 3 ncell, diagnostic download
   double *d_stateT = nullptr;      // 6 ncell: k_pack_state's products in mesh order (3 ncell), then in (j,i,k) order
   bool packed_valid = false;       // the mesh-ordered half matches xh_av / xhe_av (a complete global pass wrote it)
+  bool transposed_valid = false;   // ... and the (j,i,k)-ordered half too (that pass queued k_transpose_packed behind itself)
   size_t chem_cells = 0;           // cells the open global pass has been asked to do so far
   double *d_rc_last = nullptr;     // 12: coefficients left by the last cell of the chemistry pass
   double *d_stat = nullptr;        // STAT_BLOCKS*5 partials + 8 results
@@ -1504,6 +1505,7 @@ struct c2r_ctx {
   hipStream_t stream3 = nullptr;    // takes every other slab of a cut rates launch (kernel tails overlap)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_transposed = nullptr; // the (j,i,k)-ordered state copies of this pass are complete
+  hipEvent_t ev_chem_done = nullptr;  // the launches of a global pass are through (its transposition waits for this)
   hipEvent_t ev_sweep_done[2] = {nullptr, nullptr}, ev_rates_done[2] = {nullptr, nullptr};
   bool set_busy[2] = {false, false};
   std::vector<hipEvent_t> ev_pool; // timing events, grown on demand
@@ -1697,6 +1699,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
     CR(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CR(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CR(hipEventCreateWithFlags(&c->ev_transposed, hipEventDisableTiming));
+    CR(hipEventCreateWithFlags(&c->ev_chem_done, hipEventDisableTiming));
   }
   for (int i = 0; i < 2; i++) {
     CR(hipEventCreateWithFlags(&c->ev_sweep_done[i], hipEventDisableTiming));
@@ -1826,6 +1829,7 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_transposed) (void)hipEventDestroy(c->ev_transposed);
+  if (c->ev_chem_done) (void)hipEventDestroy(c->ev_chem_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1971,7 +1975,7 @@ static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], dou
   c->zred = zred; c->H0 = H0; c->Omega0 = Omega0;
   c->isothermal = isothermal ? 1 : 0;
   c->have_step = true;
-  c->packed_valid = false; // ndens may have changed
+  c->packed_valid = c->transposed_valid = false; // ndens may have changed
   return 0;
 }
 
@@ -2236,7 +2240,7 @@ static StepScalars scalars(c2r_ctx *c) {
 static int begin_step_one(c2r_ctx *c) {
   if (!c) return 1;
   if (!c->have_state) return fail(c, "c2r_begin_step: c2r_upload_state has not been called");
-  c->packed_valid = false; // xh_av, xhe_av are overwritten below
+  c->packed_valid = c->transposed_valid = false; // xh_av, xhe_av are overwritten below
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
   HIPCHK(c, hipMemcpyAsync(c->d_xh_av, c->d_xh, sizeof(double) * 2 * nc, hipMemcpyDeviceToDevice, c->stream));
@@ -2510,14 +2514,16 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     // order and in (j,i,k) order: made on the third stream while the inner shells, which do without them, are
     // already on their way
     HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_sweep_done[0], 0));
-    if (c->packed_valid)
+    if (c->packed_valid && c->transposed_valid) {
+      // nothing to make: the global pass transposed its own products (ev_transposed is on record since then)
+    } else if (c->packed_valid)
       hipLaunchKernelGGL(k_transpose_packed, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, 3 * g.n3), dim3(BLOCK), 0, c->stream3, g,
                          c->d_stateT, c->d_stateT + 3 * nc);
     else
       hipLaunchKernelGGL(k_pack_state, dim3((g.n1 + 31) / 32, (g.n2 + 31) / 32, g.n3), dim3(BLOCK), 0, c->stream3, g, c->d_ndens, c->d_xh_av,
                          c->d_xhe_av, c->d_stateT, c->d_stateT + 3 * nc);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev_transposed, c->stream3));
+    if (!(c->packed_valid && c->transposed_valid)) HIPCHK(c, hipEventRecord(c->ev_transposed, c->stream3));
   }
   bool transposed_seen = false; // the sweep stream has waited for ev_transposed
   const bool packed_early = c->packed_valid; // the mesh-ordered products need not wait for anything
@@ -3266,6 +3272,7 @@ extern "C" int c2r_evolve0d_global(c2r_ctx *c, double dt, const int pos[3], int 
   if (ensure_chemistry_buffers(c)) return 1;
   const size_t q = (size_t)(pos[0] - 1) + (size_t)g.n1 * ((size_t)(pos[1] - 1) + (size_t)g.n2 * (size_t)(pos[2] - 1));
   HIPCHK(c, hipMemsetAsync(c->d_conv, 0, sizeof(int), c->stream));
+  c->transposed_valid = false; // the launch keeps the mesh-ordered products of its cell up to date, not their (j,i,k) copy
   if (launch_chemistry(c, c->stream, dt, q, 1, nullptr, 0, c->d_defer[0], c->d_chemctl)) return 1;
   if (fold_chemistry_counters(c, c->stream)) return 1;
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -3355,7 +3362,7 @@ extern "C" int c2r_global_pass_cells(c2r_ctx *c, double dt, size_t first_cell, s
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_sweep_done[0], 0));
     c->tm.chem_launches = 0;
     c->chem_pieces = 0;
-    c->packed_valid = false;
+    c->packed_valid = c->transposed_valid = false;
     c->chem_cells = 0;
     c->chem_dt = dt;
   }
@@ -3427,6 +3434,24 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
   }
   if (c->isothermal && fold_chemistry_counters(c, c->stream)) return 1;
   if (c->timing) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  // every cell's products for the next column sweep are up to date if the pieces of this pass covered the mesh
+  // (pieces that overlap or leave gaps, a caller's business, leave the flag down: the next pass then packs anew)
+  // C2R_PACK_AT_PASS_START=1 (diagnostic): never rely on the global pass's copy
+  static const bool pack_always = getenv("C2R_PACK_AT_PASS_START") && atoi(getenv("C2R_PACK_AT_PASS_START")) > 0;
+  const bool packed_now = c->chem_cells == c->g.ncell && !pack_always;
+  // C2R_TRANSPOSE_AT_PASS_START=1 (diagnostic): the transposition at the start of the next pass, as before round 3
+  static const bool transpose_late = getenv("C2R_TRANSPOSE_AT_PASS_START") && atoi(getenv("C2R_TRANSPOSE_AT_PASS_START")) > 0;
+  if (packed_now && !transpose_late) {
+    // ... and their (j,i,k)-ordered copy is made right away, on the third stream, while the host reads this pass's
+    // results: at the start of the next pass it would share the device with the sweep's innermost shells (measured: 9-14
+    // us each beside it, 5-7 us alone)
+    HIPCHK(c, hipEventRecord(c->ev_chem_done, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_chem_done, 0));
+    hipLaunchKernelGGL(k_transpose_packed, dim3((c->g.n1 + 31) / 32, (c->g.n2 + 31) / 32, 3 * c->g.n3), dim3(BLOCK), 0, c->stream3, c->g,
+                       c->d_stateT, c->d_stateT + 3 * c->g.ncell);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_transposed, c->stream3));
+  }
   if (c->want_iter_stats) {
     // c2r_iteration: the grid reductions the host loop wants after this pass, behind it in the same queue
     double *partial = c->d_iter, *partial_min = c->d_iter + (size_t)STAT_BLOCKS * ITER_NV, *res = partial_min + (size_t)STAT_BLOCKS * 2;
@@ -3447,11 +3472,8 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     c->tm.chem_ms = ms;
   }
   if (conv_flag) *conv_flag = *c->h_conv;
-  // every cell's products for the next column sweep are up to date if the pieces of this pass covered the mesh
-  // (pieces that overlap or leave gaps, a caller's business, leave the flag down: the next pass then packs anew)
-  // C2R_PACK_AT_PASS_START=1 (diagnostic): never rely on the global pass's copy
-  static const bool pack_always = getenv("C2R_PACK_AT_PASS_START") && atoi(getenv("C2R_PACK_AT_PASS_START")) > 0;
-  c->packed_valid = c->chem_cells == c->g.ncell && !pack_always;
+  c->packed_valid = packed_now;
+  c->transposed_valid = packed_now && !transpose_late;
   return 0;
 }
 
@@ -3515,7 +3537,7 @@ static int upload_rates_one(c2r_ctx *c, const double *phih, const double *phihe,
 static int upload_iter_state_one(c2r_ctx *c, const double *xh_av, const double *xhe_av, const double *xh_intermed,
                                      const double *xhe_intermed) {
   if (!c) return 1;
-  c->packed_valid = false;
+  c->packed_valid = c->transposed_valid = false;
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nc = c->g.ncell;
   if (xh_av) HIPCHK(c, hipMemcpyAsync(c->d_xh_av, xh_av, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
