@@ -127,6 +127,38 @@ __host__ __device__ inline size_t col_out(size_t p, int k, size_t cz) {
   return (C2R_COLS_AOS == 1 || C2R_COLS_AOS == 3) ? 3 * cz + 3 * p + (size_t)k : p + (size_t)(3 + k) * cz;
 }
 
+// The sweep's stores of a cell's six columns.  C2R_SWEEP_NT: 1 = the incoming columns, which only the rates launch
+// reads, long after, as non-temporal stores: they then do not sit dirty in the L2s until the end of the launch, when
+// every XCD writes its cache back before the next shell may start (a launch per shell: up to 32 MB each time).
+// 2 = the outgoing ones as well.  Measured at 256^3 x 8, same box, ms per pass (sweep | rates): isothermal 0: 3.98-4.03
+// | 18.5, 1: 3.82 | 18.5, 2: 3.78-3.83 | 18.4; with heating 0: 3.86 | 27.9, 1: 3.63 | 28.0-28.1, 2: 3.69 | 28.3 -- the
+// rates launch reads non-temporally written columns a little slower, so only the incoming ones are stored that way.
+// (Non-temporal LOADS of the columns in the rates kernel: +0.4 ms per launch, neighbouring cubes share their lines.)
+#ifndef C2R_SWEEP_NT
+#define C2R_SWEEP_NT 1
+#endif
+__device__ __forceinline__ void store_columns(global_double *cs, size_t p, size_t cz, double cin_HI, double cin_HeI, double cin_HeII,
+                                              double cout_HI, double cout_HeI, double cout_HeII) {
+#if C2R_SWEEP_NT >= 1
+  __builtin_nontemporal_store(cin_HI, &cs[col_in(p, 0, cz)]);
+  __builtin_nontemporal_store(cin_HeI, &cs[col_in(p, 1, cz)]);
+  __builtin_nontemporal_store(cin_HeII, &cs[col_in(p, 2, cz)]);
+#else
+  cs[col_in(p, 0, cz)] = cin_HI;
+  cs[col_in(p, 1, cz)] = cin_HeI;
+  cs[col_in(p, 2, cz)] = cin_HeII;
+#endif
+#if C2R_SWEEP_NT >= 2
+  __builtin_nontemporal_store(cout_HI, &cs[col_out(p, 0, cz)]);
+  __builtin_nontemporal_store(cout_HeI, &cs[col_out(p, 1, cz)]);
+  __builtin_nontemporal_store(cout_HeII, &cs[col_out(p, 2, cz)]);
+#else
+  cs[col_out(p, 0, cz)] = cout_HI;
+  cs[col_out(p, 1, cz)] = cout_HeI;
+  cs[col_out(p, 2, cz)] = cout_HeII;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // What the sweep needs of a cell's state, once per pass instead of once per cell.source: the three products
 // neufrac * ndens of coldens (doric.f90:358-372: neufrac*ndens*path*abundance is evaluated from the left, so the
@@ -451,12 +483,7 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs &A, const SrcDev &S, 
   const double cout_HI = cin_HI + u_HI * path * (1.0 - abu_he);
   const double cout_HeI = cin_HeI + u_HeI * path * abu_he;
   const double cout_HeII = cin_HeII + u_HeII * path * abu_he;
-  cs[col_in(p, 0, cz)] = cin_HI;
-  cs[col_in(p, 1, cz)] = cin_HeI;
-  cs[col_in(p, 2, cz)] = cin_HeII;
-  cs[col_out(p, 0, cz)] = cout_HI;
-  cs[col_out(p, 1, cz)] = cout_HeI;
-  cs[col_out(p, 2, cz)] = cout_HeII;
+  store_columns(cs, p, cz, cin_HI, cin_HeI, cin_HeII, cout_HI, cout_HeI, cout_HeII);
 }
 
 // The same for a shell s >= 2, with everything that is common to the cells of one shell taken out of the cell's
@@ -498,12 +525,7 @@ __device__ __forceinline__ void sweep_cell_fast(const SweepArgs &A, const SrcDev
   const double cout_HI = cin_HI + u_HI * path * (1.0 - abu_he);
   const double cout_HeI = cin_HeI + u_HeI * path * abu_he;
   const double cout_HeII = cin_HeII + u_HeII * path * abu_he;
-  cs[col_in(p, 0, cz)] = cin_HI;
-  cs[col_in(p, 1, cz)] = cin_HeI;
-  cs[col_in(p, 2, cz)] = cin_HeII;
-  cs[col_out(p, 0, cz)] = cout_HI;
-  cs[col_out(p, 1, cz)] = cout_HeI;
-  cs[col_out(p, 2, cz)] = cout_HeII;
+  store_columns(cs, p, cz, cin_HI, cin_HeI, cin_HeII, cout_HI, cout_HeI, cout_HeII);
 }
 
 // Which 256 cells of a shell of `cnt` cells a block takes (-1: none).  Blocks are dealt round-robin over the 8 XCDs,
