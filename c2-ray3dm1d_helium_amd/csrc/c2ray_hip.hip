@@ -2641,8 +2641,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     hipEvent_t e_s0 = nullptr, e_s1 = nullptr, e_r0 = nullptr, e_r1 = nullptr;
     if (c->timing) {
       if (pool_event(c, &e_s0) || pool_event(c, &e_s1) || pool_event(c, &e_r0) || pool_event(c, &e_r1)) return 1;
-      HIPCHK(c, hipEventRecord(e_s0, c->stream));
     }
+    bool sweep_started = false; // e_s0 goes in front of the first shell launch, behind the uploads of records and lists
     size_t list_used = 0;
     long long batch_cells = 0;
     int *hl = c->h_list[set];
@@ -2800,6 +2800,10 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       SA.g = g; SA.box = box; SA.sc = sc;
       SA.ndens = c->d_ndens; SA.xh_av = c->d_xh_av; SA.xhe_av = c->d_xhe_av;
       SA.lls_grid = c->lls_on_grid ? c->d_lls : nullptr;
+      if (c->timing && !sweep_started) {
+        HIPCHK(c, hipEventRecord(e_s0, c->stream));
+        sweep_started = true;
+      }
       for (int s = s_lo; s <= s_hi; s++) {
         // (a large batch waits at once: its many small faces would pay more for strided reads than the wait costs)
         if ((s >= TRANSPOSED_FROM_SHELL || nb > 16) && !transposed_seen) {
@@ -2870,8 +2874,11 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       }
       c->prev_nbox[(size_t)run[b].ns - 1] = run[b].nbox;
     }
+    if (c->timing) { // the sweep's span: from the first shell launch to the last, record uploads on either side left out
+      if (!sweep_started) HIPCHK(c, hipEventRecord(e_s0, c->stream));
+      HIPCHK(c, hipEventRecord(e_s1, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_src[set], c->h_src[set], sizeof(SrcDev) * nb, hipMemcpyHostToDevice, c->stream));
-    if (c->timing) HIPCHK(c, hipEventRecord(e_s1, c->stream));
     if (!transposed_seen) {
       // small boxes only: nobody needed the copies, but whatever follows this sweep (the global pass rewrites the
       // state) has to come after the kernel that reads it
