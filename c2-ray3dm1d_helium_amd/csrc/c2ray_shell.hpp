@@ -122,34 +122,28 @@ inline uint32_t mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t
 // shell_decode for the shell of G; also tells the face: 0 = k-face (z-plane crossing, column_density.f90:107),
 // 1 = j-face (y-plane crossing, :199), 2 = i-face (x-plane crossing, :275)
 C2R_HD int shell_decode_fast(const ShellGeom &G, int t, int &di, int &dj, int &dk) {
+  // One straight line with selects on VALUES: written as three branches that assign di, dj, dk in different roles,
+  // the compiler merged the assignments into stores through a selected pointer -- the three offsets went to scratch
+  // memory and came back with a full wait each, in every thread of the sweep.
   const int s = G.s;
-  if (t < 2 * G.A) {
-    const bool neg = t >= G.A;
-    const uint32_t u = (uint32_t)(neg ? t - G.A : t);
-    const uint32_t r = mulhi_u32(u, G.mw) >> G.kw;
-    dk = neg ? -s : s;
-    dj = (int)r - s;
-    di = (int)(u - r * (uint32_t)G.w) - s;
-    return 0;
-  }
-  if (t < 2 * G.A + 2 * G.B) {
-    t -= 2 * G.A;
-    const bool neg = t >= G.B;
-    const uint32_t u = (uint32_t)(neg ? t - G.B : t);
-    const uint32_t r = mulhi_u32(u, G.mw) >> G.kw;
-    dj = neg ? -s : s;
-    dk = (int)r - (s - 1);
-    di = (int)(u - r * (uint32_t)G.w) - s;
-    return 1;
-  }
-  t -= 2 * G.A + 2 * G.B;
-  const bool neg = t >= G.C;
-  const uint32_t u = (uint32_t)(neg ? t - G.C : t);
-  const uint32_t r = mulhi_u32(u, G.mv) >> G.kv;
-  di = neg ? -s : s;
-  dk = (int)r - (s - 1);
-  dj = (int)(u - r * (uint32_t)G.v) - (s - 1);
-  return 2;
+  const int face = t < 2 * G.A ? 0 : (t < 2 * G.A + 2 * G.B ? 1 : 2);
+  const int first = face == 0 ? 0 : (face == 1 ? 2 * G.A : 2 * G.A + 2 * G.B); // first cell of the pair of faces
+  const int size = face == 0 ? G.A : (face == 1 ? G.B : G.C);                  // cells of one face
+  const int width = face == 2 ? G.v : G.w;                                     // cells of one row
+  const uint32_t magic = face == 2 ? G.mv : G.mw;
+  const int shift = face == 2 ? G.kv : G.kw;
+  const int tf = t - first;
+  const bool neg = tf >= size;
+  const uint32_t u = (uint32_t)(neg ? tf - size : tf);
+  const uint32_t r = mulhi_u32(u, magic) >> shift;          // the row
+  const int col = (int)(u - r * (uint32_t)width);           // the place in the row
+  const int a = col - (face == 2 ? s - 1 : s);              // the coordinate that runs fastest
+  const int b = (int)r - (face == 0 ? s : s - 1);           // the one that counts the rows
+  const int c = neg ? -s : s;                               // the one that is fixed on the face
+  di = face == 2 ? c : a;
+  dj = face == 0 ? b : (face == 1 ? c : a);
+  dk = face == 0 ? c : b;
+  return face;
 }
 
 // position within shell s-1 (without its shell_offset) of a cell known to lie in that shell: max(|i|,|j|,|k|) == s-1
