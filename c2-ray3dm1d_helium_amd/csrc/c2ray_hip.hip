@@ -73,9 +73,12 @@ struct StepScalars {
 };
 
 __device__ __forceinline__ int wrap0(int x, int n) { // 0-based periodic index of x in [-n, 2n)
-  if (x < 0) x += n;
-  else if (x >= n) x -= n;
-  return x;
+  // of x, x + n and x - n exactly one lies in [0, n); read as unsigned numbers it is the smallest of the three
+  // (v_add, v_sub, v_min3_u32 instead of two compares, two selects and the arithmetic)
+  const unsigned u = (unsigned)x, m = (unsigned)n;
+  const unsigned a = u + m, b = u - m;
+  const unsigned lo = a < b ? a : b;
+  return (int)(u < lo ? u : lo);
 }
 __device__ __forceinline__ size_t cell_index(const Grid &g, int i0, int j0, int k0, int di, int dj, int dk) {
   int i = wrap0(i0 - 1 + di, g.n1), j = wrap0(j0 - 1 + dj, g.n2), k = wrap0(k0 - 1 + dk, g.n3);
@@ -423,8 +426,9 @@ __device__ __forceinline__ void sweep_cell_state(const SweepArgs &A, int i, int 
   if (A.packed) {
     const bool tr = iface && A.packedT; // (the inner shells run before the (j,i,k)-ordered copy exists: strided reads)
     const double *P = tr ? A.packedT : A.packed;
-    const size_t q = tr ? (size_t)j + (size_t)g.n2 * ((size_t)i + (size_t)g.n1 * (size_t)k)
-                        : (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+    // a mesh has fewer than 2^31 cells (c2r_create): the cell number in 32 bits, one widening for the address
+    const unsigned q = tr ? (unsigned)j + (unsigned)g.n2 * ((unsigned)i + (unsigned)g.n1 * (unsigned)k)
+                          : (unsigned)i + (unsigned)g.n1 * ((unsigned)j + (unsigned)g.n2 * (unsigned)k);
     u_HI = P[q];
     u_HeI = P[q + nc];
     u_HeII = P[q + 2 * nc];
@@ -2816,7 +2820,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         const int nblk = c->block_base[s + 1] - c->block_base[s];
         // from 64 blocks on: a multiple of 8 blocks, one contiguous eighth of the shell per XCD (see the kernel)
         const int nlaunch = nblk >= 64 ? ((nblk + 7) & ~7) : nblk;
-        if (s >= 2 && !generic_sweep)
+        if (s >= 2 && s <= SHELL_FAST_MAX && !generic_sweep)
           hipLaunchKernelGGL(k_sweep_shell_fast, dim3(nlaunch, nact), dim3(BLOCK), 0, c->stream, SA, c->d_src[set],
                              c->d_list[set] + act_off, c->shell_geom[(size_t)s]);
         else

@@ -75,6 +75,7 @@ C2R_HD size_t shell_position(int di, int dj, int dk) {
 //     up to 4096; tests/test_device_functions_host.py): those are read from the nearest cell of shell s - 1 instead
 //     (any finite value gives the same bits), so that every corner's position follows from the face formulas of
 //     ONE known shell, without the general inverse map.
+constexpr int SHELL_FAST_MAX = 640; // (2s+1)^3 < 2^31: positions within a source's shell-ordered arrays fit 32 bits
 struct ShellGeom {
   int s, w, v;        // the shell, 2s+1, 2s-1
   int A, B, C;        // w*w, v*w, v*v: cells of one k-, j-, i-face
@@ -161,7 +162,7 @@ C2R_HD int position_in_previous_shell(const ShellGeom &G, int i, int j, int k) {
 // operations on the same values as short_characteristic (c2ray_device.hpp) -- the diagonal factors of
 // column_density.f90:174-184 only occur in shell 1 --, with the per-shell constants of ShellGeom.
 struct ShellCorners {
-  long long p[4];
+  uint32_t p[4]; // positions in the shell-ordered arrays: 32 bits hold them up to shell 645 (SHELL_FAST_MAX)
   double s[4];
   double path;
 };
@@ -190,14 +191,15 @@ C2R_HD void shell_short_characteristic(const ShellGeom &G, int face, int i0, int
   // corners (am|da, bm|db) in the plane one step closer to the source; a coordinate beyond shell s-1 (the cell sits
   // on an edge of its face) belongs to a corner of weight exactly 0: take the nearest cell of shell s-1 instead
   const int ca = da > sp ? sp : (da < -sp ? -sp : da), cb = db > sp ? sp : (db < -sp ? -sp : db);
+  const uint32_t offp = (uint32_t)G.offp;
   if (face == 0) {
     const int km = dk > 0 ? sp : -sp;
     const int base = (km > 0 ? 0 : G.Ap) + sp;
     const int ra = base + (bm + sp) * G.wp, rb = base + (cb + sp) * G.wp;
-    sc.p[0] = G.offp + (ra + am);
-    sc.p[1] = G.offp + (ra + ca);
-    sc.p[2] = G.offp + (rb + am);
-    sc.p[3] = G.offp + (rb + ca);
+    sc.p[0] = offp + (uint32_t)(ra + am);
+    sc.p[1] = offp + (uint32_t)(ra + ca);
+    sc.p[2] = offp + (uint32_t)(rb + am);
+    sc.p[3] = offp + (uint32_t)(rb + ca);
   } else if (face == 1) {
     const int jm = dj > 0 ? sp : -sp;
     // a row (fixed k') of the plane j' = jm lies in a k-face of shell s-1 if |k'| == s-1, else in its j-face
@@ -205,22 +207,24 @@ C2R_HD void shell_short_characteristic(const ShellGeom &G, int face, int i0, int
     const int bma = bm < 0 ? -bm : bm, cba = cb < 0 ? -cb : cb;
     const int ra = bma == sp ? (bm > 0 ? 0 : G.Ap) + rk_base : rj_base + bm * G.wp;
     const int rb = cba == sp ? (cb > 0 ? 0 : G.Ap) + rk_base : rj_base + cb * G.wp;
-    sc.p[0] = G.offp + (ra + am);
-    sc.p[1] = G.offp + (ra + ca);
-    sc.p[2] = G.offp + (rb + am);
-    sc.p[3] = G.offp + (rb + ca);
+    sc.p[0] = offp + (uint32_t)(ra + am);
+    sc.p[1] = offp + (uint32_t)(ra + ca);
+    sc.p[2] = offp + (uint32_t)(rb + am);
+    sc.p[3] = offp + (uint32_t)(rb + ca);
   } else {
     const int im = di > 0 ? sp : -sp;
-    sc.p[0] = G.offp + position_in_previous_shell(G, im, am, bm);
-    sc.p[1] = G.offp + position_in_previous_shell(G, im, ca, bm);
-    sc.p[2] = G.offp + position_in_previous_shell(G, im, am, cb);
-    sc.p[3] = G.offp + position_in_previous_shell(G, im, ca, cb);
+    sc.p[0] = offp + (uint32_t)position_in_previous_shell(G, im, am, bm);
+    sc.p[1] = offp + (uint32_t)position_in_previous_shell(G, im, ca, bm);
+    sc.p[2] = offp + (uint32_t)position_in_previous_shell(G, im, am, cb);
+    sc.p[3] = offp + (uint32_t)position_in_previous_shell(G, im, ca, cb);
   }
 }
 
 // 1 / max(0.6, cd * sig) (weightf, column_density.f90:351-376): the argument of the reciprocal lies in
 // [0.6, 1.2e291] for every finite column, where recip_nr (the division's own instruction sequence without operand
 // scaling) is exact
+// (the maximum as a bare v_max_f64 (dmax_const) saves 24 instructions per cell and was measured SLOWER: 3.71-3.74
+// against 3.61-3.62 ms per sweep on one box; so was nothing gained by a square root without operand scaling)
 C2R_HD double weightf_fast(double cd, double sig) { return recip_nr(dmax(0.6, cd * sig)); }
 
 // weighted mean of the four corner columns of one species (column_density.f90:145-163) with those weights

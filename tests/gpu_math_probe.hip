@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #ifdef C2R_PROBE_USE_PRODUCT_MATH
-#include "../c2-ray3dm1d_helium_amd/csrc/c2ray_device.hpp"
+#include "../c2-ray3dm1d_helium_amd/csrc/c2ray_shell.hpp"
 #else
 #define C2R_MATH_EXP(x) exp(x)
 #define C2R_MATH_LOG10(x) log10(x)
@@ -19,6 +19,7 @@ __global__ void k_probe(int op, int n, const double *x, const double *y, double 
     case 2: r = C2R_MATH_POW(x[i], y[i]); break;
     case 3: r = sqrt(x[i]); break;
 #ifdef C2R_PROBE_USE_PRODUCT_MATH
+    case 13: r = c2r::weightf_fast(x[i], y[i]); break;             // must equal 1 / max(0.6, x * y)
     case 5: r = c2r::recip_nr(x[i]); break;                       // must equal 1.0 / x
     case 6: case 7: case 8: {                                      // div_by_vol: must equal a / b, all three
       const c2r::Recip R = c2r::make_recip(y[i]);

@@ -76,6 +76,19 @@ def test_reciprocal_and_volume_division_bit_exact(probe):
         assert np.array_equal(run(probe, 8, a, b), np.zeros(n))
 
 
+def test_sweep_weight_bit_exact(probe):
+    """The column sweep's 1/max(0.6, N sigma) with the division's sequence minus operand scaling (c2ray_shell.hpp)
+    against the IEEE operations."""
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    cd = 10.0 ** rng.uniform(-5, 30, n)
+    cd[:1000] = 0.0
+    sig = np.full(n, 6.30e-18)
+    sig[n // 2:] = 10.0 ** rng.uniform(-19, -16, n - n // 2)
+    cd[1000:2000] = 0.6 / sig[1000:2000]                                           # the maximum's switch-over
+    assert np.array_equal(run(probe, 13, cd, sig), 1.0 / np.maximum(0.6, cd * sig))
+
+
 def test_pair_table_position_equals_single(probe):
     """tau_table_positions (both logs as one straight line, polynomial path on demand) == tau_table_position."""
     rng = np.random.default_rng(8)
