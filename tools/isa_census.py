@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--asm", help="use this .s file instead of compiling")
     ap.add_argument("--out")
     ap.add_argument("--blocks", action="store_true", help="also list every basic block")
+    ap.add_argument("--scratch-scan", action="store_true", help="list every kernel of the library that has a private segment")
     a = ap.parse_args()
     if a.asm:
         asm = Path(a.asm).read_text()
@@ -156,15 +157,28 @@ def main():
             if r.returncode != 0:
                 raise SystemExit(r.stderr)
             asm = next(Path(td).glob("*gfx950.s")).read_text()
+    if a.scratch_scan:
+        kname = None
+        for ln in asm.splitlines():
+            m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", ln)
+            if m:
+                kname = m.group(1)
+            m = re.match(r"\s*\.amdhsa_private_segment_fixed_size\s+(\d+)", ln)
+            if m and int(m.group(1)) > 0:
+                print(f"{int(m.group(1)):6d} bytes  {kname}")
+        return
     name, body = kernel_text(asm, a.kernel, a.variant)
     loops, blocks = census(body)
     meta = {}
-    for key in ("next_free_vgpr", "next_free_sgpr", "accum_offset"):
+    for key in ("next_free_vgpr", "next_free_sgpr", "accum_offset", "private_segment_fixed_size"):
         m = re.search(r"\.amdhsa_" + key + r"\s+(\d+)", "\n".join(body))
         if m:
             meta[key] = int(m.group(1))
     spills = sum(1 for ln in body if "scratch_" in ln and "Spill" in ln or "Reload" in ln)
-    lines = [f"kernel {name}", f"registers {meta}  spill/reload instructions {spills}", ""]
+    # every access to the private segment, spill or not: an array the compiler could not keep in registers (a pointer
+    # selected at run time, an index it could not unroll) shows up here and nowhere else
+    scratch = sum(1 for ln in body if re.match(r"\s*scratch_(load|store)", ln))
+    lines = [f"kernel {name}", f"registers {meta}  spill/reload instructions {spills}  scratch loads+stores {scratch}", ""]
     lines.append(f"{'whole kernel':28s} {fmt(loops[('kernel', 0)])}")
     for (hdr, depth), c in sorted(((k, v) for k, v in loops.items() if k[0] != "kernel"), key=lambda kv: (kv[0][1], kv[0][0])):
         lines.append(f"loop {hdr:14s} depth {depth}   {fmt(c)}")
