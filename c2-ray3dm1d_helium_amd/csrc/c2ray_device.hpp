@@ -637,63 +637,24 @@ struct SedSums {
   double f_heat, f_ion_HI, f_ion_HeI, df_ion_HI, df_ion_HeI;
 };
 
-// One frequency band of photo_lookuptable (radiation_photoionrates.f90:331-464) + heat_lookuptable (:470-779) +
-// scale_int2/3 (:787-823).  CLS = 0: the band below the He I threshold (HI only), 1: bands NumBndin1+1 ..
-// +NumBndin2 (HI and HeI), 2: the bands above the He II threshold (all three species).  The cross sections of
-// species that cannot absorb in a band are exactly 0 (radiation_sizes.f90:382-383, :405; checked when the
-// tables are set), so their terms -- x*0 + ... with finite x -- are left out: the sums keep their bits.
-// `look_for_zero`: test whether the band is beyond the last non-zero table entry (band_tau_zero); returns
-// whether it was.  Within a class the optical depth falls from band to band, so once no lane of a wave has
-// found a band dead the caller stops asking (a missed skip costs time, never a bit).
-template <bool HEAT, int CLS, class LT>
-C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
-                       const double *heat_thin, const LT *logtab, const double *tau_zero, bool look_for_zero, int b,
-                       const CellSrc &c, const Ricotti &ric, SedSums &o) {
-  const double NFlux = c.NFlux;
-  const double sHI = bd.sigma_HI[b];
-  double sHeI = 0.0, sHeII = 0.0;
-  double tau_in = c.cin_HI * sHI, tau_out = c.cout_HI * sHI;
-  if (CLS >= 1) {
-    sHeI = bd.sigma_HeI[b];
-    tau_in = tau_in + c.cin_HeI * sHeI;
-    tau_out = tau_out + c.cout_HeI * sHeI;
-  }
-  if (CLS >= 2) {
-    sHeII = bd.sigma_HeII[b];
-    tau_in = tau_in + c.cin_HeII * sHeII;
-    tau_out = tau_out + c.cout_HeII * sHeII;
-  }
-  if (look_for_zero && tau_in >= tau_zero[b]) {
-    // every table entry this band would read is exactly 0 (tau_out >= tau_in): all its rates are +0 and no sum
-    // changes; what the reference's band would leave behind in df_ion is +0 as well
-    if (HEAT && CLS >= 1) o.df_ion_HI = o.df_ion_HeI = 0.0;
-    return true;
-  }
-  const double dtau = tau_out - tau_in;
-  const bool thick = fabs(dtau) > tau_photo_limit;
-  const bool hthick = fabs(dtau) > tau_heat_limit;
-  // both positions always: an optically thin band (no use for pout) is rare, and one straight line for the
-  // two logs is worth more than skipping one of them now and then
+// What one band adds to ONE SED's sums (the lookuptable bodies proper), given everything of the band that does not
+// depend on the SED: the cross sections, both table positions, the species split and the thick/thin decisions.
+struct BandShared {
+  double sHI, sHeI, sHeII;
+  double dtau;
+  bool thick, hthick;
   TauPos pin, pout;
-  tau_table_positions(tau_in, tau_out, logtab, pin, pout, c.pins);
-
-  // species split of this band (scale_int2 / scale_int3)
-  double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
-  if (CLS == 1) {
-    const double tH = sHI * c.cell_HI, tHe = sHeI * c.cell_HeI;
-    const double den = tH + tHe;
-    const double forscaleing = c.recip_safe ? recip_nr(den) : 1.0 / den;
-    sc_HI = tH * forscaleing;
-    sc_HeI = tHe * forscaleing;
-  } else if (CLS == 2) {
-    const double tH = sHI * c.cell_HI, tHe = sHeI * c.cell_HeI, tHe2 = sHeII * c.cell_HeII;
-    const double den = tH + tHe + tHe2;
-    const double forscaleing = c.recip_safe ? recip_nr(den) : 1.0 / den;
-    sc_HI = tH * forscaleing;
-    sc_HeI = tHe * forscaleing;
-    sc_HeII = tHe2 * forscaleing;
-  }
-
+  double sc_HI, sc_HeI, sc_HeII;
+};
+template <bool HEAT, int CLS>
+C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
+                     const double *heat_thin, int b, const CellSrc &c, double NFlux, const BandShared &B, const Ricotti &ric,
+                     SedSums &o) {
+  const double sHI = B.sHI, sHeI = B.sHeI, sHeII = B.sHeII, dtau = B.dtau;
+  const bool thick = B.thick, hthick = B.hthick;
+  const TauPos pin = B.pin, pout = B.pout;
+  const double sc_HI = B.sc_HI, sc_HeI = B.sc_HeI, sc_HeII = B.sc_HeII;
+  (void)sHeI; (void)sHeII; (void)sc_HI; (void)sc_HeI; (void)sc_HeII; (void)hthick;
   // photo_lookuptable body
   {
     const double *tk = photo_thick + (size_t)b * NTAUP;
@@ -809,10 +770,105 @@ C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const doub
     o.f_ion_HI = o.f_ion_HI + o.df_ion_HI;
     o.f_ion_HeI = o.f_ion_HeI + o.df_ion_HeI;
   }
+}
+
+// The optical depths of band b at the two faces of the cell, and the band's cross sections (into B)
+template <int CLS>
+C2R_HD void band_depths(const BandData &bd, int b, const CellSrc &c, BandShared &B, double &tau_in, double &tau_out) {
+  const double sHI = bd.sigma_HI[b];
+  double sHeI = 0.0, sHeII = 0.0;
+  tau_in = c.cin_HI * sHI;
+  tau_out = c.cout_HI * sHI;
+  if (CLS >= 1) {
+    sHeI = bd.sigma_HeI[b];
+    tau_in = tau_in + c.cin_HeI * sHeI;
+    tau_out = tau_out + c.cout_HeI * sHeI;
+  }
+  if (CLS >= 2) {
+    sHeII = bd.sigma_HeII[b];
+    tau_in = tau_in + c.cin_HeII * sHeII;
+    tau_out = tau_out + c.cout_HeII * sHeII;
+  }
+  B.sHI = sHI; B.sHeI = sHeI; B.sHeII = sHeII;
+}
+// ... and the rest of what the band's SEDs share: thick or thin, both table positions, the species split
+template <int CLS, class LT>
+C2R_HD void band_positions(const LT *logtab, const CellSrc &c, double tau_in, double tau_out, BandShared &B) {
+  const double dtau = tau_out - tau_in;
+  B.dtau = dtau;
+  B.thick = fabs(dtau) > tau_photo_limit;
+  B.hthick = fabs(dtau) > tau_heat_limit;
+  // both positions always: an optically thin band (no use for pout) is rare, and one straight line for the
+  // two logs is worth more than skipping one of them now and then
+  tau_table_positions(tau_in, tau_out, logtab, B.pin, B.pout, c.pins);
+  // species split of this band (scale_int2 / scale_int3)
+  double sc_HI = 1.0, sc_HeI = 0.0, sc_HeII = 0.0;
+  if (CLS == 1) {
+    const double tH = B.sHI * c.cell_HI, tHe = B.sHeI * c.cell_HeI;
+    const double den = tH + tHe;
+    const double forscaleing = c.recip_safe ? recip_nr(den) : 1.0 / den;
+    sc_HI = tH * forscaleing;
+    sc_HeI = tHe * forscaleing;
+  } else if (CLS == 2) {
+    const double tH = B.sHI * c.cell_HI, tHe = B.sHeI * c.cell_HeI, tHe2 = B.sHeII * c.cell_HeII;
+    const double den = tH + tHe + tHe2;
+    const double forscaleing = c.recip_safe ? recip_nr(den) : 1.0 / den;
+    sc_HI = tH * forscaleing;
+    sc_HeI = tHe * forscaleing;
+    sc_HeII = tHe2 * forscaleing;
+  }
+  B.sc_HI = sc_HI; B.sc_HeI = sc_HeI; B.sc_HeII = sc_HeII;
+}
+
+// One frequency band of photo_lookuptable (radiation_photoionrates.f90:331-464) + heat_lookuptable (:470-779) +
+// scale_int2/3 (:787-823).  CLS = 0: the band below the He I threshold (HI only), 1: bands NumBndin1+1 ..
+// +NumBndin2 (HI and HeI), 2: the bands above the He II threshold (all three species).  The cross sections of
+// species that cannot absorb in a band are exactly 0 (radiation_sizes.f90:382-383, :405; checked when the
+// tables are set), so their terms -- x*0 + ... with finite x -- are left out: the sums keep their bits.
+// `look_for_zero`: test whether the band is beyond the last non-zero table entry (band_tau_zero); returns
+// whether it was.  Within a class the optical depth falls from band to band, so once no lane of a wave has
+// found a band dead the caller stops asking (a missed skip costs time, never a bit).
+template <bool HEAT, int CLS, class LT>
+C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
+                       const double *heat_thin, const LT *logtab, const double *tau_zero, bool look_for_zero, int b,
+                       const CellSrc &c, const Ricotti &ric, SedSums &o) {
+  BandShared B;
+  double tau_in, tau_out;
+  band_depths<CLS>(bd, b, c, B, tau_in, tau_out);
+  if (look_for_zero && tau_in >= tau_zero[b]) {
+    // every table entry this band would read is exactly 0 (tau_out >= tau_in): all its rates are +0 and no sum
+    // changes; what the reference's band would leave behind in df_ion is +0 as well
+    if (HEAT && CLS >= 1) o.df_ion_HI = o.df_ion_HeI = 0.0;
+    return true;
+  }
+  band_positions<CLS, LT>(logtab, c, tau_in, tau_out, B);
+  band_sed<HEAT, CLS>(bd, photo_thick, photo_thin, heat_thick, heat_thin, b, c, c.NFlux, B, ric, o);
   return false;
 }
 
-
+// The same band for TWO SEDs that cover it (the power-law and the quasar-like SED of the -DPL -DQUASARS builds share
+// their band range): optical depths, logs, table positions and species split once, then each SED's look-ups and sums
+// exactly as band_rates makes them -- every sum sees the same operands in the same order.  dead[k]: band_rates' return
+// value for SED k.
+template <bool HEAT, int CLS, class LT>
+C2R_HD void band_rates_pair(const BandData &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
+                            const double *const (&heat_thick)[2], const double *const (&heat_thin)[2], const LT *logtab,
+                            const double *const (&tau_zero)[2], const bool (&look_for_zero)[2], int b, const CellSrc &c,
+                            const double (&NFlux)[2], const Ricotti &ric, SedSums (&o)[2], bool (&dead)[2]) {
+  BandShared B;
+  double tau_in, tau_out;
+  band_depths<CLS>(bd, b, c, B, tau_in, tau_out);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    dead[k] = look_for_zero[k] && tau_in >= tau_zero[k][b];
+    if (dead[k] && HEAT && CLS >= 1) o[k].df_ion_HI = o[k].df_ion_HeI = 0.0;
+  }
+  if (dead[0] && dead[1]) return;
+  band_positions<CLS, LT>(logtab, c, tau_in, tau_out, B);
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (!dead[k]) band_sed<HEAT, CLS>(bd, photo_thick[k], photo_thin[k], heat_thick[k], heat_thin[k], b, c, NFlux[k], B, ric, o[k]);
+}
 
 // what one photo_lookuptable + heat_lookuptable pair of calls returns for one SED (before the sums of
 // radiation_photoionrates.f90:178-262 put them together)
@@ -878,6 +934,57 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
 }
 
 
+// sed_rates for two SEDs with the same band range at once (band_rates_pair): out[k] is bit for bit what
+// sed_rates(tables of k, NFlux[k]) returns
+template <bool HEAT, class LT>
+C2R_HD void sed_rates_pair(const BandData &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
+                           const double *const (&heat_thick)[2], const double *const (&heat_thin)[2], int blo, int bhi,
+                           double cin_HI, double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII,
+                           double vol, const double (&NFlux)[2], const Ricotti &ric, SedAcc (&out)[2], const LT *logtab,
+                           const double *const (&tau_zero)[2], const gm::LogPins *pins = nullptr) {
+  CellSrc c;
+  c.cin_HI = cin_HI; c.cin_HeI = cin_HeI; c.cin_HeII = cin_HeII;
+  c.cout_HI = cout_HI; c.cout_HeI = cout_HeI; c.cout_HeII = cout_HeII;
+  c.cell_HI = cout_HI - cin_HI;
+  c.cell_HeI = cout_HeI - cin_HeI;
+  c.cell_HeII = cout_HeII - cin_HeII;
+  c.NFlux = 0.0; // per SED: handed to band_rates_pair
+  c.rvol = make_recip(vol);
+  c.pins = pins;
+  c.recip_safe = column_in_recip_range(c.cell_HI) && column_in_recip_range(c.cell_HeI) && column_in_recip_range(c.cell_HeII);
+  SedSums o[2] = {{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}};
+  const int e0 = bhi < NB1 ? bhi : NB1, e1 = bhi < NB1 + NB2 ? bhi : NB1 + NB2;
+  int b = blo;
+  bool look[2] = {true, true}, dead[2];
+  for (; b < e0; b++) {
+    band_rates_pair<HEAT, 0, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, NFlux, ric, o, dead);
+    look[0] = any_lane(dead[0]); look[1] = any_lane(dead[1]);
+  }
+  look[0] = look[1] = true;
+  for (; b < e1; b++) {
+    band_rates_pair<HEAT, 1, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, NFlux, ric, o, dead);
+    look[0] = any_lane(dead[0]); look[1] = any_lane(dead[1]);
+  }
+  look[0] = look[1] = true;
+  for (; b < bhi; b++) {
+    band_rates_pair<HEAT, 2, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, logtab, tau_zero, look, b, c, NFlux, ric, o, dead);
+    look[0] = any_lane(dead[0]); look[1] = any_lane(dead[1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    out[k].photo_HI = o[k].photo_HI;
+    out[k].photo_HeI = o[k].photo_HeI;
+    out[k].photo_HeII = o[k].photo_HeII;
+    out[k].photo_out = o[k].photo_out;
+    out[k].f_heat = out[k].f_ion_HI = out[k].f_ion_HeI = 0.0;
+    if (HEAT) {
+      out[k].f_heat = o[k].f_heat;
+      out[k].f_ion_HI = o[k].f_ion_HI;
+      out[k].f_ion_HeI = o[k].f_ion_HeI;
+    }
+  }
+}
+
 // photoion_rates for a source with the black-body SED only
 template <bool HEAT, class LT = double>
 C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
@@ -920,16 +1027,32 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
-  // one band loop per SED over its own band range, like the reference's lookuptable calls (the tau
-  // positions of a band shared by two SEDs are evaluated twice: ranges rarely overlap -- BB 1..33,
-  // PL and QPL 38..47 in the nominal set-up -- and one loop at a time needs far fewer registers)
+  // one band loop per SED over its own band range, like the reference's lookuptable calls (BB 1..33, PL and QPL
+  // 38..47 in the nominal set-up)
   SedAcc a[NSED];
   bool act[NSED];
-  for (int s = 0; s < NSED; s++) {
-    act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
+  for (int s = 0; s < NSED; s++) act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
+  // the two extra SEDs over the same bands (the nominal set-up: both 38..47): one band loop for both (band_rates_pair)
+#if defined(C2R_NO_SED_PAIR) // diagnostic build: one band loop per SED, as before round 3
+  const bool pair = false;
+#else
+  const bool pair = act[1] && act[2] && ss.lo[1] == ss.lo[2] && ss.hi[1] == ss.hi[2];
+#endif
+  for (int s = 0; s < (pair ? 1 : NSED); s++) {
     if (act[s])
       sed_rates<HEAT, LT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
                           cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s], pins);
+  }
+  if (pair) {
+    const double *const pt[2] = {ss.photo_thick[1], ss.photo_thick[2]}, *const pn[2] = {ss.photo_thin[1], ss.photo_thin[2]};
+    const double *const ht[2] = {ss.heat_thick[1], ss.heat_thick[2]}, *const hn[2] = {ss.heat_thin[1], ss.heat_thin[2]};
+    const double *const tz[2] = {bd.tau_zero[1], bd.tau_zero[2]};
+    const double nf[2] = {NFlux[1], NFlux[2]};
+    SedAcc a2[2];
+    sed_rates_pair<HEAT, LT>(bd, pt, pn, ht, hn, ss.lo[1], ss.hi[1], cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, nf,
+                             ric, a2, logtab, tz, pins);
+    a[1] = a2[0];
+    a[2] = a2[1];
   }
   // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
   for (int s = 0; s < NSED; s++) {
