@@ -3280,12 +3280,14 @@ static int ensure_chemistry_buffers(c2r_ctx *c) {
   if (!c->d_chemspread) {
     const size_t bytes = sizeof(int) * (size_t)CHEM_CTL_COPIES * CHEM_CTL_STRIDE;
     HIPCHK(c, hipMalloc(&c->d_chemspread, bytes));
-    HIPCHK(c, hipMemset(c->d_chemspread, 0, bytes)); // k_chem_ctl_reduce leaves it zeroed every time
+    // (on the main stream, which the first launch follows -- or waits for through an event: a hipMemset on the null
+    // stream is not ordered with launches on non-blocking streams); k_chem_ctl_reduce leaves it zeroed every time
+    HIPCHK(c, hipMemsetAsync(c->d_chemspread, 0, bytes, c->stream));
   }
   if (!c->isothermal && !c->d_defer[0]) {
     for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
     HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST))); // two list counts, then the histogram
-    HIPCHK(c, hipMemset(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST)));
+    HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST), c->stream));
   }
   return 0;
 }

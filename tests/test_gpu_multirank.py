@@ -223,4 +223,4 @@ def test_replicas_of_one_process_share_the_sources(pkg, gold, nrep):
     fused = _iterate(eb, dt, 3, fused=True)
     eb.close()
     for k, v in plain.items():
-        assert np.array_equal(np.asarray(v), np.asarray(fused[k])), k
+        assert np.array_equal(np.asarray(v), np.asarray(fused[k])), (k, "non-converged counts, plain / slab-wise:", plain["conv"], fused["conv"])
