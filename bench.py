@@ -237,7 +237,23 @@ def main():
     e.upload_state(mat)
     e.set_batch(batch)
     e.enable_timing(True)
-    comm = pkg.parallel.RcclComm(e, dist) if dist is not None else None
+    comm = None
+    transport = None
+    if dist is not None:
+        try:
+            if os.environ.get("C2R_BENCH_FAIL_LIB_COMM"):     # rehearses the fall-back below on one GPU
+                raise RuntimeError("forced by C2R_BENCH_FAIL_LIB_COMM")
+            comm = pkg.parallel.RcclComm(e, dist)
+            transport = "RCCL all-reduce of the rate grids inside the library (c2r_comm_init + ncclAllReduce, slab-wise, overlapped)"
+        except Exception as ex:  # noqa: BLE001 -- whatever the library reports: no RCCL to load, version, init error
+            # The library's communicator has never met a second GPU.  If it cannot be set up -- the
+            # same on every rank: nothing has been exchanged yet but the id -- the bench still measures the path, with the
+            # same slab-wise overlapped sum carried by torch.distributed's RCCL instead, and SAYS SO in its result line.
+            sys.stderr.write(f"bench.py: rank {rank}: the library's RCCL communicator failed ({ex}); "
+                             "falling back to torch.distributed (backend nccl = RCCL) for the sum over ranks\n")
+            e.use_torch_rates_buffer(f"cuda:{local}")   # the reduction buffer as a tensor torch.distributed can sum in place
+            comm = pkg.parallel.TorchComm(dist.new_group(backend="nccl"))
+            transport = f"FALL-BACK: torch.distributed nccl (= RCCL) all-reduce of the rate grids, slab-wise, overlapped; the library's own communicator failed: {ex}"
     dt = 1.0e7 * pkg.hostphys.YEAR
     e.begin_step()
 
@@ -310,7 +326,7 @@ def main():
                                     f"{'neutral start, ' if a.neutral_start else ''}one evolve3D outer iteration per step"),
                        "mesh": n, "sources_per_gpu": per_gpu, "batch": batch, "coverage": coverage,
                        "swept_cell_updates_per_s": swept_total / elapsed,
-                       "parallelism": f"sources over {world} GPU(s), RCCL all-reduce of the rate grids inside the library, replicated chemistry"},
+                       "parallelism": f"sources over {world} GPU(s), replicated chemistry; sum over ranks: {transport or 'none (one rank)'}"},
             # the dominant kernel on ITS OWN compulsory bytes: six columns per cell.source, state and rate grids per cell
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
