@@ -72,3 +72,19 @@ def test_hot_kernels_keep_nothing_in_scratch_memory(pkg, tmp_path):
     hot = [n for n in seg if re.search(r"k_sweep_shell|k_chemistry|k_loss|k_pack_state|k_transpose_packed|7k_ratesILb[01]ELb0E", n)]
     assert len(hot) >= 10, sorted(seg)
     assert {n: seg[n] for n in hot if seg[n]} == {}
+
+
+def test_no_null_stream_fills_outside_context_creation():
+    """hipMemset / hipMemcpy without a stream run on the null stream, which is ordered with nothing on the library's
+    non-blocking streams: a fill issued lazily, next to launches, can land after them (round 3: the deferred-cell
+    counters of the heating tiers).  Such calls may only appear where a device-wide synchronisation follows before
+    any launch (c2r_create) or where the call itself blocks the host on data the host owns (hipMemcpy)."""
+    src = (ROOT / "c2-ray3dm1d_helium_amd" / "csrc" / "c2ray_hip.hip").read_text()
+    start = src.index('extern "C" int c2r_create(')
+    end = src.index('extern "C" void c2r_destroy(')
+    outside = src[:start] + src[end:]
+    assert "hipMemset(" not in outside
+    assert "hipMemset(" not in (ROOT / "c2-ray3dm1d_helium_amd" / "csrc" / "c2ray_comm.inc").read_text()
+    # inside c2r_create the fills are followed by a device synchronisation
+    create = src[start:end]
+    assert create.rindex("hipDeviceSynchronize()") > create.rindex("hipMemset(")
