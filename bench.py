@@ -8,9 +8,18 @@ ranks when N > 1, and the global chemistry pass.  Inputs are resident in HBM bef
 
     python bench.py --gpus N --steps K --warmup W [--workload config3|config4]
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  The sum over ranks is an RCCL all-reduce INSIDE
-the library (c2r_comm_init / c2r_pass_allreduce_chemistry, include/c2ray_hip.h); torch.distributed (gloo) only
-carries the 128-byte RCCL id to the ranks and does the barrier / max-over-ranks of this harness.
+N > 1, three ways to get there -- the sum over ranks is an RCCL all-reduce INSIDE the library in all of them
+(c2r_comm_init[_local] / c2r_pass_allreduce_chemistry, include/c2ray_hip.h):
+  * launched by torch.distributed.run (WORLD_SIZE set), one rank per GPU: c2r_create + c2r_comm_init
+    (ncclCommInitRank); torch.distributed (gloo) only carries the 128-byte RCCL id to the ranks and does the barrier /
+    max-over-ranks of this harness;
+  * `python bench.py --gpus N` with no launcher (WORLD_SIZE unset), the default: ONE process drives the N GPUs
+    through c2r_create_multi + c2r_comm_init_local (ncclCommInitAll), one host thread per device inside the
+    library -- how the reference's no_mpi build reaches a whole node; nothing of torch.distributed is involved;
+  * `python bench.py --gpus N --launcher children`: this process, before it touches torch or HIP, starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child and relays its result line.
+`rccl_ranks` in the result line is what c2r_comm_nranks reports for an RCCL communicator (0 when the sum over ranks
+was carried by anything else).
 
   --workload config3 (default; BASELINE configs[2]): every rank sweeps --sources sources of its own (weak
       scaling: per-GPU work fixed); value = mesh^3 x (sources x N) x K / max-over-ranks time.
@@ -174,6 +183,26 @@ def cpu_baseline_reference(mesh=64):
                       f"isothermal, {niter} outer iterations of evolve3D in {total:.1f} s (nominal mesh^3 x sources per iteration, as the metric)"}
 
 
+def launch_children(a):
+    """`python bench.py --gpus N --launcher children`: start the N ranks as a CHILD torch.distributed.run and relay the one
+    result line.  Runs before this process has imported torch or touched HIP (a process that has may not exec or be
+    replaced; a child is always fine)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [x for x in sys.argv[1:] if x != "children" and x != "--launcher" and not x.startswith("--launcher=")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    if r.returncode != 0 or not lines:
+        raise SystemExit(r.returncode or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,10 +217,20 @@ def main():
                     help="non-isothermal variant (heating tables, thermal evolution); not the headline config")
     ap.add_argument("--neutral-start", action="store_true",
                     help="config3 from the reference's neutral test-problem start (small sub-boxes, chemistry in its expensive state)")
+    ap.add_argument("--one-process", action="store_true",
+                    help="one process drives all --gpus devices (c2r_create_multi + c2r_comm_init_local); the default for "
+                         "--gpus N > 1 when no launcher set WORLD_SIZE; with --gpus 1 a one-device RCCL communicator")
+    ap.add_argument("--launcher", choices=["none", "children"], default="none",
+                    help="children: start torch.distributed.run with --gpus ranks as a child process and relay its result")
     a = ap.parse_args()
 
     # dmabuf IPC for RCCL's peer-to-peer transport on this driver (must be set before the HIP runtime starts)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1        # torch.distributed.run (or another launcher) made us a rank
+    if not launched and a.launcher == "children" and not a.one_process:   # also with --gpus 1 (rehearsal)
+        return launch_children(a)
+    one_process = a.one_process or (a.gpus > 1 and not launched)
+
     # stdout carries ONE line, the result: whatever libraries print there while they start up (gloo, RCCL's version
     # banner) goes to stderr instead
     sys.stdout.flush()
@@ -200,16 +239,26 @@ def main():
 
     import torch
     pkg = ge.load_package()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if one_process:
+        world, rank, local = a.gpus, 0, 0
+        have = pkg._lib.load().c2r_device_count()
+        # C2R_BENCH_SHARE_DEVICE=1: all "devices" are GPU 0 (rehearsal on a one-GPU box: RCCL refuses duplicate devices,
+        # the library then sums its replicas itself and rccl_ranks says 0)
+        share = bool(os.environ.get("C2R_BENCH_SHARE_DEVICE"))
+        if have < a.gpus and not share:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} HIP device(s) visible")
+        devices = [0] * a.gpus if share else list(range(a.gpus))
+    else:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if a.gpus != world:
+            raise SystemExit(f"bench.py --gpus {a.gpus} inside a launch of WORLD_SIZE={world}")
+        devices = local
     torch.cuda.set_device(local)
     dist = None
     force_comm = bool(os.environ.get("C2R_BENCH_FORCE_COMM"))   # rehearses the N > 1 code path (RCCL, one rank) on one GPU
-    if world > 1 or force_comm:
+    if not one_process and (world > 1 or force_comm):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -230,7 +279,7 @@ def main():
         mat, grid, src, cosmo = config3_inputs(pkg, n, total_src, heating=a.heating, neutral=a.neutral_start)
         batch = a.batch or 8
     tables = pkg.RadiationTables.load()
-    e = pkg.HipEngine((n, n, n), local)
+    e = pkg.HipEngine((n, n, n), devices)
     e.set_tables(tables)
     e.set_step(mat, grid, cosmo)
     e.set_sources(src)
@@ -239,21 +288,28 @@ def main():
     e.enable_timing(True)
     comm = None
     transport = None
-    if dist is not None:
+    if one_process:
+        e.comm_init_local()       # ncclCommInitAll over this process's devices; failure is fatal: there is no other transport here
+        comm = pkg.parallel.LocalComm(e)
+        transport = (f"one process, {a.gpus} device(s): RCCL all-reduce of the rate grids inside the library (c2r_create_multi + "
+                     "c2r_comm_init_local = ncclCommInitAll, slab-wise, overlapped)") if e.rccl_ranks() else \
+                    f"one process, {a.gpus} replicas SHARING ONE DEVICE (rehearsal): summed by the library itself, no RCCL"
+    elif dist is not None:
         try:
-            if os.environ.get("C2R_BENCH_FAIL_LIB_COMM"):     # rehearses the fall-back below on one GPU
-                raise RuntimeError("forced by C2R_BENCH_FAIL_LIB_COMM")
-            comm = pkg.parallel.RcclComm(e, dist)
-            transport = "RCCL all-reduce of the rate grids inside the library (c2r_comm_init + ncclAllReduce, slab-wise, overlapped)"
+            fail = os.environ.get("C2R_BENCH_FAIL_LIB_COMM")     # rehearses the fall-back below: "1" every rank, "rank0" rank 0 only
+            comm = pkg.parallel.RcclComm(e, dist, fail_on_ranks=() if not fail else ((0,) if fail == "rank0" else range(world)))
+            transport = "RCCL all-reduce of the rate grids inside the library (c2r_comm_init = ncclCommInitRank, slab-wise, overlapped)"
         except Exception as ex:  # noqa: BLE001 -- whatever the library reports: no RCCL to load, version, init error
-            # The library's communicator has never met a second GPU.  If it cannot be set up -- the
-            # same on every rank: nothing has been exchanged yet but the id -- the bench still measures the path, with the
-            # same slab-wise overlapped sum carried by torch.distributed's RCCL instead, and SAYS SO in its result line.
+            # The library's communicator has never met a second GPU.  If it cannot be set up --
+            # RcclComm makes that decision collectively: every rank is here, or none -- the bench still measures the path,
+            # with the same slab-wise overlapped sum carried by torch.distributed's RCCL instead, and SAYS SO in its result
+            # line (rccl_ranks 0): a diagnostic, never the result.
             sys.stderr.write(f"bench.py: rank {rank}: the library's RCCL communicator failed ({ex}); "
                              "falling back to torch.distributed (backend nccl = RCCL) for the sum over ranks\n")
             e.use_torch_rates_buffer(f"cuda:{local}")   # the reduction buffer as a tensor torch.distributed can sum in place
             comm = pkg.parallel.TorchComm(dist.new_group(backend="nccl"))
             transport = f"FALL-BACK: torch.distributed nccl (= RCCL) all-reduce of the rate grids, slab-wise, overlapped; the library's own communicator failed: {ex}"
+    rccl_ranks = e.rccl_ranks()
     dt = 1.0e7 * pkg.hostphys.YEAR
     e.begin_step()
 
@@ -266,11 +322,12 @@ def main():
         return e.global_pass(dt)
 
     def barrier():
-        e.synchronize()
-        torch.cuda.synchronize()
+        e.synchronize()           # every device of the context
+        for d in (sorted(set(devices)) if one_process else [local]):
+            torch.cuda.synchronize(d)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         step()
@@ -278,6 +335,8 @@ def main():
     sweep_ms = rates_ms = chem_ms = 0.0
     swept = 0
     rates_launches = 0
+    ndev_here = a.gpus if one_process else 1
+    other = [{"swept": 0, "sweep_ms": 0.0, "rates_ms": 0.0, "chem_ms": 0.0} for _ in range(ndev_here - 1)]
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -287,6 +346,12 @@ def main():
         chem_ms += tm.chem_ms
         swept += tm.cells_swept
         rates_launches += tm.rates_launches
+        for i, o in enumerate(other):     # the other devices of a one-process run
+            t = e.timing(i + 1)
+            o["swept"] += t.cells_swept
+            o["sweep_ms"] += t.sweep_ms
+            o["rates_ms"] += t.rates_ms
+            o["chem_ms"] += t.chem_ms
     barrier()
     elapsed = time.perf_counter() - t0
     mine = {"elapsed": elapsed, "swept": swept, "sweep_ms": sweep_ms, "rates_ms": rates_ms, "chem_ms": chem_ms}
@@ -294,7 +359,7 @@ def main():
         allr = [None] * world
         dist.all_gather_object(allr, mine)
     else:
-        allr = [mine]
+        allr = [mine] + [{"elapsed": elapsed, **o} for o in other]
     elapsed = max(r["elapsed"] for r in allr)
     swept_total = sum(r["swept"] for r in allr)
 
@@ -317,6 +382,9 @@ def main():
             "value": units / elapsed, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "strong" if cfg4 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # ranks of the RCCL communicator INSIDE the library that summed the rate grids (c2r_comm_nranks; 0: one rank
+            # without communicator, a fall-back transport, or replicas sharing a device)
+            "rccl_ranks": rccl_ranks,
             "config": {"workload": (f"BASELINE configs[3]: {n}^3 log-normal density, {total_src} sources dealt over {world} GPU(s) "
                                     f"({per_gpu} on rank 0), neutral start, {'heating' if heating else 'isothermal 1e4 K'}, one evolve3D "
                                     f"outer iteration per step (the state evolves from step to step)") if cfg4 else
@@ -372,9 +440,11 @@ def main():
         for k in ("roofline_evolve0d", "roofline_column_sweep", "roofline_chemistry"):
             if k in out:
                 out[k]["frac"] = out[k]["achieved"] / HBM_PEAK_GBS
+        out["config"]["launch"] = ("one process, c2r_create_multi" if one_process else
+                                   "one process per GPU (torch.distributed.run)" if world > 1 else "one process, one GPU")
         if world > 1:
             # per-rank step time (imbalance) and what the kernels of a step do not account for (exposed sum over ranks,
-            # host time)
+            # host time); in a one-process run every device shares the one wall clock
             out["per_rank_ms_per_step"] = [1e3 * r["elapsed"] / a.steps for r in allr]
             out["per_rank_kernel_ms_per_step"] = [(r["sweep_ms"] + r["rates_ms"]) / a.steps for r in allr]   # pass only (see above)
         if headline and DROPIN_TIMING.exists():

@@ -97,16 +97,19 @@ SYMBOLS = {
     "c2r_device_count": (C.c_int, []),
     "c2r_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _ip, _ip]),
     "c2r_num_devices": (C.c_int, [C.c_void_p]),
+    "c2r_comm_available": (C.c_int, []),
     "c2r_comm_unique_id": (C.c_int, [C.c_char_p]),
     "c2r_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "c2r_comm_init_local": (C.c_int, [C.c_void_p]),
     "c2r_comm_destroy": (C.c_int, [C.c_void_p]),
     "c2r_comm_rank": (C.c_int, [C.c_void_p]),
     "c2r_comm_nranks": (C.c_int, [C.c_void_p]),
+    "c2r_comm_kind": (C.c_int, [C.c_void_p]),
     "c2r_allreduce_rates": (C.c_int, [C.c_void_p]),
     "c2r_pass_allreduce_chemistry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _ip]),
     "c2r_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(IterationReport)]),
     "c2r_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "c2r_get_timing_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Timing)]),
     "c2r_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
 }
 

@@ -167,6 +167,15 @@ class HipEngine:
             raise C2RayHipError(lib.c2r_create_error().decode())
         return buf.raw
 
+    @staticmethod
+    def comm_available():
+        """None when RCCL can be loaded and used by this library, else the reason (a string)."""
+        lib = _lib.load()
+        return None if lib.c2r_comm_available() == 0 else lib.c2r_create_error().decode()
+
+    def comm_destroy(self):
+        self._chk(self.lib.c2r_comm_destroy(self.h))
+
     def comm_init(self, first_rank, nranks, unique_id):
         assert len(unique_id) == 128
         self._chk(self.lib.c2r_comm_init(self.h, int(first_rank), int(nranks), unique_id))
@@ -176,6 +185,11 @@ class HipEngine:
 
     def comm_size(self):
         return int(self.lib.c2r_comm_nranks(self.h))
+
+    def rccl_ranks(self):
+        """Ranks of the RCCL communicator that sums the rate grids (0: no communicator, or the in-process sum of
+        replicas that share a device)."""
+        return self.comm_size() if int(self.lib.c2r_comm_kind(self.h)) == 1 else 0
 
     def num_devices(self):
         return int(self.lib.c2r_num_devices(self.h))
@@ -378,9 +392,12 @@ class HipEngine:
     def enable_timing(self, on=True):
         self._chk(self.lib.c2r_enable_timing(self.h, int(on)))
 
-    def timing(self):
+    def timing(self, idev=None):
         t = _lib.Timing()
-        self._chk(self.lib.c2r_get_timing(self.h, C.byref(t)))
+        if idev is None:
+            self._chk(self.lib.c2r_get_timing(self.h, C.byref(t)))
+        else:
+            self._chk(self.lib.c2r_get_timing_device(self.h, int(idev), C.byref(t)))
         return t
 
     # -- outputs -----------------------------------------------------------------------------

@@ -365,6 +365,11 @@ module c2ray_hip
        type(c_ptr), value :: ctx
      end function c2r_comm_nranks
 
+     integer(c_int) function c2r_comm_kind(ctx) bind(C, name="c2r_comm_kind")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_comm_kind
+
      integer(c_int) function c2r_allreduce_rates(ctx) bind(C, name="c2r_allreduce_rates")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -108,15 +108,51 @@ class RcclComm:
     rank 0 to the others (any backend) and the barrier / max-over-ranks of the timing harness; nothing of it is
     in the data path."""
 
-    def __init__(self, engine, dist=None):
+    def __init__(self, engine, dist=None, fail_on_ranks=()):
+        """Collective over `dist`: either every rank leaves with a communicator or every rank raises the same
+        error (and holds none) -- a rank that failed alone would leave the others waiting inside the collective
+        ncclCommInitRank, or inside the broadcast of the id.  Three agreements, each over torch.distributed:
+        (1) every rank can load RCCL (c2r_comm_available), (2) rank 0 obtained the id (the error text travels in
+        its place), (3) every rank's c2r_comm_init succeeded.  fail_on_ranks: ranks that pretend step (1) failed
+        (rehearsal of the fall-back in bench.py and tests/test_host_logic.py)."""
         self.engine = engine
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
         self.size = dist.get_world_size() if dist is not None else 1
-        uid = [type(engine).comm_unique_id() if self.rank == 0 else None]
-        if dist is not None and self.size > 1:
-            dist.broadcast_object_list(uid, src=0)
-        engine.comm_init(self.rank, self.size, uid[0])
+        many = dist is not None and self.size > 1
+
+        def agree(err):
+            """None when no rank reports an error, else the first rank's text (the same on every rank)."""
+            if not many:
+                return err
+            errs = [None] * self.size
+            dist.all_gather_object(errs, err)
+            return next((f"rank {r}: {e}" for r, e in enumerate(errs) if e is not None), None)
+
+        err = "forced failure (rehearsal)" if self.rank in tuple(fail_on_ranks) else type(engine).comm_available()
+        err = agree(err)
+        if err is not None:
+            raise RuntimeError(f"RCCL is not usable on every rank: {err}")
+        box = [None]
+        if self.rank == 0:
+            try:
+                box[0] = ("id", type(engine).comm_unique_id())
+            except Exception as ex:  # noqa: BLE001 -- travels to the other ranks instead of the id
+                box[0] = ("error", str(ex))
+        if many:
+            dist.broadcast_object_list(box, src=0)
+        if box[0][0] != "id":
+            raise RuntimeError(f"rank 0 could not obtain the RCCL id: {box[0][1]}")
+        err = None
+        try:
+            engine.comm_init(self.rank, self.size, box[0][1])
+        except Exception as ex:  # noqa: BLE001
+            err = str(ex)
+        all_err = agree(err)
+        if all_err is not None:
+            if err is None:
+                engine.comm_destroy()
+            raise RuntimeError(f"c2r_comm_init failed: {all_err}")
 
     def allreduce_rates(self, engine=None):
         self.engine.allreduce_rates()
@@ -130,6 +166,30 @@ class RcclComm:
         if nslab is None:
             nslab = int(os.environ.get("C2R_ALLREDUCE_SLABS", "4"))
         return self.engine.pass_allreduce_chemistry(dt, 1 + self.rank, self.size, nslab)
+
+
+class LocalComm:
+    """One process, the devices of a c2r_create_multi context with c2r_comm_init_local's communicators
+    (ncclCommInitAll): the reference's no_mpi build on a whole node.  The library deals the sources over its devices
+    (device i: 1 + i, 1 + i + ndev, ...), sums over them and replicates the chemistry; this host sees one rank."""
+    rank = 0
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.size = 1        # ranks of THIS host loop: the split over the devices is the library's
+
+    def allreduce_rates(self, engine=None):
+        self.engine.allreduce_rates()
+
+    def pass_and_allreduce(self, engine=None, nslab=None):
+        self.engine.pass_sources(1, 1)
+        self.engine.allreduce_rates()
+
+    def pass_allreduce_chemistry(self, engine, dt, nslab=None):
+        import os
+        if nslab is None:
+            nslab = int(os.environ.get("C2R_ALLREDUCE_SLABS", "4"))
+        return self.engine.pass_allreduce_chemistry(dt, 1, 1, nslab)
 
 
 class SingleComm:

@@ -253,12 +253,20 @@ int c2r_set_batch(c2r_ctx *ctx, int nbatch);
 int c2r_device_count(void);
 int c2r_create_multi(c2r_ctx **out, int ndev, const int *devices, const int mesh[3]);
 int c2r_num_devices(const c2r_ctx *ctx);
+/* 0 when librccl can be loaded and reports the major version this library was compiled against (what
+ * c2r_comm_unique_id / c2r_comm_init need); otherwise non-zero with the reason in c2r_create_error().  Lets every
+ * rank of a launcher agree BEFORE the collective ncclCommInitRank whether the communicator can be made at all. */
+int c2r_comm_available(void);
 int c2r_comm_unique_id(char id[128]);
 int c2r_comm_init(c2r_ctx *ctx, int first_rank, int nranks, const char id[128]);
 int c2r_comm_init_local(c2r_ctx *ctx);
 int c2r_comm_destroy(c2r_ctx *ctx);
 int c2r_comm_rank(const c2r_ctx *ctx);
 int c2r_comm_nranks(const c2r_ctx *ctx);
+/* What carries the sum over ranks (MPI_ALLREDUCE in evolve.F90:505-548): 0 nothing (one rank, no communicator),
+ * 1 RCCL (ncclAllReduce), 2 the in-process sum of replicas that share a device (rehearsal mode of
+ * c2r_comm_init_local).  A harness reports c2r_comm_nranks as "ranks RCCL saw" only when this is 1. */
+int c2r_comm_kind(const c2r_ctx *ctx);
 /* mpi_accumulate_grid_quantities (evolve.F90:505-548) after c2r_pass_sources: the whole buffer in one
  * all-reduce; afterwards c2r_get_loss / c2r_download_rates return the summed photon_loss and sum_nbox_all.
  * A no-op on a single rank without communicator.  On a multi-device context c2r_pass_sources(first, stride)
@@ -317,6 +325,8 @@ typedef struct {
   long long cells_swept; /* cell x source pairs actually traced by the last c2r_pass_sources */
 } c2r_timing;
 int c2r_get_timing(c2r_ctx *ctx, c2r_timing *out);
+/* the same for device `idev` (0 .. c2r_num_devices-1) of a context made by c2r_create_multi */
+int c2r_get_timing_device(c2r_ctx *ctx, int idev, c2r_timing *out);
 int c2r_enable_timing(c2r_ctx *ctx, int on);
 
 #ifdef __cplusplus

@@ -67,3 +67,31 @@ def tap_case(z, call):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def collect_from_ranks(procs, q, nresults=1, timeout=300):
+    """Results that worker processes put on `q`, without waiting out a long time-out in silence when a worker died:
+    polls the queue, fails as soon as a worker has exited with an error, and ends every worker when time is up."""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < nresults:
+        try:
+            out.append(q.get(timeout=2))
+            continue
+        except queue.Empty:
+            pass
+        dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+        if dead or time.time() - t0 > timeout:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+            raise AssertionError(f"worker ranks failed: exit codes {[p.exitcode for p in procs]}" if dead else
+                                 f"no result from the worker ranks within {timeout} s")
+    for p in procs:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+            raise AssertionError("a worker rank did not exit")
+        assert p.exitcode == 0, [p.exitcode for p in procs]
+    return out[0] if nresults == 1 else out

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from conftest import ROOT, tap_case
+from conftest import ROOT, collect_from_ranks, tap_case
 
 pytestmark = pytest.mark.gpu
 
@@ -49,11 +49,7 @@ def _run_ranks(pipelined, port, world=2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, pipelined)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=600)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    return res
+    return collect_from_ranks(procs, q)
 
 
 def test_two_ranks_on_one_gpu(pkg, gold):
@@ -224,3 +220,127 @@ def test_replicas_of_one_process_share_the_sources(pkg, gold, nrep):
     eb.close()
     for k, v in plain.items():
         assert np.array_equal(np.asarray(v), np.asarray(fused[k])), (k, "non-converged counts, plain / slab-wise:", plain["conv"], fused["conv"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# More than one REAL device: RCCL (ncclCommInitAll / ncclCommInitRank + ncclAllReduce) inside the library.
+# Skipped on the one-GPU box; they run wherever `pytest -m gpu` meets two devices.
+
+def _device_count(pkg):
+    return int(pkg._lib.load().c2r_device_count())
+
+
+def _oracle_two_ranks(pkg, gold, niter, case="tap_N16_heat_3src.npz", call=2):
+    """`niter` outer iterations of the oracle with the sources dealt over two ranks as do_grid_static does and the
+    rate grids summed as a two-rank all-reduce does: (s1 + s3) + s2."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as orc
+    from oracle_engine import OracleEngine
+    from test_host_logic import _inputs
+    with np.load(pkg.evolve.DEFAULT_TABLES) as t:
+        T = orc.Tables({k: t[k] for k in t.files})
+    i, _, mesh, mat, grid, src, cosmo = _inputs(pkg, gold, case, call)
+    e = OracleEngine(mesh, T)
+    e.set_step(mat, grid, cosmo)
+    e.set_sources(src)
+    e.upload_state(mat)
+    e.begin_step()
+    conv = []
+    for _ in range(niter):
+        parts = []
+        for r in range(2):
+            e.set_rates_to_zero()
+            e.pass_sources(1 + r, 2)
+            parts.append((e.s.phih.copy(), e.s.phihe.copy(), e.s.phiheat.copy(), e.loss, e.nbox))
+        a, b = parts
+        e.s.phih[:], e.s.phihe[:], e.s.phiheat[:] = a[0] + b[0], a[1] + b[1], a[2] + b[2]
+        e.loss, e.nbox = a[3] + b[3], a[4] + b[4]
+        conv.append(e.global_pass(float(i["dt"][0])))
+    out = {**e.download_rates(), **e.download_iter_state()}
+    out["conv"] = conv
+    return out
+
+
+def _same_as_oracle(got, ref):
+    assert got["conv"] == ref["conv"]
+    for k in ("phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av", "xh_intermed", "xhe_intermed"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert got["sum_nbox"] == ref["sum_nbox"]
+    assert abs(got["photon_loss"][0] / ref["photon_loss"][0] - 1) < 1e-13   # block-ordered sum on the device
+
+
+def test_two_devices_rccl_vs_oracle(pkg, gold):
+    """ONE process, two GPUs: c2r_create_multi([0, 1]) + c2r_comm_init_local (ncclCommInitAll); three fused outer
+    iterations (pass, slab-wise ncclAllReduce, slab-wise global pass) against the oracle run with the same
+    association of the sum, bit for bit; then pass -> whole-buffer all-reduce -> global pass, the same bits again
+    (two ranks: a + b == b + a whatever the ring does)."""
+    if _device_count(pkg) < 2:
+        pytest.skip("needs two HIP devices")
+    ref = _oracle_two_ranks(pkg, gold, 3)
+    for fused in (True, False):
+        e, dt, _ = _engine(pkg, gold, [0, 1])
+        e.comm_init_local()
+        assert e.num_devices() == 2 and e.rccl_ranks() == 2
+        got = _iterate(e, dt, 3, fused=fused)
+        e.close()
+        _same_as_oracle(got, ref)
+
+
+def _rccl_rank(rank, world, port, q, fused):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    gold = lambda n: np.load(ROOT / "tests" / "golden" / n)
+    e, dt, _ = _engine(pkg, gold, rank)                  # one process per GPU: device = rank
+    comm = pkg.parallel.RcclComm(e, dist)                # c2r_comm_unique_id on rank 0, gloo carries it, c2r_comm_init
+    assert e.rccl_ranks() == world
+    got = _iterate(e, dt, 3, fused=fused, first=1 + rank, stride=world)
+    if rank == 0:
+        q.put(got)
+    dist.barrier()
+    e.close()
+    dist.destroy_process_group()
+
+
+def test_two_processes_rccl_vs_oracle(pkg, gold):
+    """One process per GPU, the launch shape of torch.distributed.run / MPI: c2r_create(rank) + c2r_comm_init
+    (ncclCommInitRank) with the id carried by gloo; same comparison as above."""
+    if _device_count(pkg) < 2:
+        pytest.skip("needs two HIP devices")
+    ref = _oracle_two_ranks(pkg, gold, 3)
+    ctx = mp.get_context("spawn")
+    for n, fused in enumerate((True, False)):
+        q = ctx.Queue()
+        port = 33100 + (os.getpid() % 2000) + n
+        procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, q, fused)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = collect_from_ranks(procs, q)
+        _same_as_oracle(got, ref)
+
+
+def test_all_devices_of_the_node_rccl(pkg, gold):
+    """Every device of the box in one process (3 sources over up to 8 devices: most sweep nothing and still owe their
+    share of every sum).  With more than two ranks the ring's association is RCCL's own: agreement with the serial
+    oracle to rounding per pass, and the slab-wise sums against the whole-buffer sum likewise."""
+    nd = min(8, _device_count(pkg))
+    if nd < 3:
+        pytest.skip("needs three or more HIP devices")
+    _, o = tap_case(gold("tap_N16_heat_3src.npz"), 2)
+    res = []
+    for fused in (True, False):
+        e, dt, _ = _engine(pkg, gold, list(range(nd)))
+        e.comm_init_local()
+        assert e.rccl_ranks() == nd
+        res.append(_iterate(e, dt, 3, fused=fused))
+        e.close()
+    a, b = res
+    assert a["sum_nbox"] == b["sum_nbox"]
+    for k in ("phih_grid", "phihe_grid", "phiheat"):
+        scale = np.maximum(np.abs(b[k]), 1e-300)
+        assert np.max(np.abs(a[k] - b[k]) / scale) < 1e-12, k
+    assert np.all(np.isfinite(a["xh_intermed"])) and np.max(np.abs(a["xh_intermed"] - b["xh_intermed"])) < 1e-6

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, tap_case
+from conftest import ROOT, collect_from_ranks, tap_case
 
 sys.path.insert(0, str(ROOT / "tests"))
 
@@ -106,10 +106,7 @@ def test_two_ranks_gloo_sources_sharded(pkg, gold):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, fname, call, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = q.get(timeout=600)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = collect_from_ranks(procs, q, timeout=600)
     assert abs(res["niter"] - len(o["conv_flags"])) <= 2
     assert res["nbox"] == int(o["sum_nbox_all"][0])
     assert abs(res["loss"] / o["photon_loss_all"][0] - 1) < 1e-9
@@ -140,3 +137,71 @@ def test_mpi_lines_of_the_fortran_shim_compile(tmp_path):
     # and the lines are really there (an #ifdef that hides nothing proves nothing)
     text = (src / "evolve.F90").read_text() + (src / "evolve_data.F90").read_text()
     assert text.count("MPI_BCAST") >= 10 and "MPI_ABORT" in text
+
+
+# ---------------------------------------------------------------------------------------------------------
+# parallel.RcclComm sets its communicator up COLLECTIVELY: every rank leaves with one, or every rank raises.
+
+class _FakeRcclEngine:
+    """The four calls RcclComm makes, with failures injected per rank (no GPU, no RCCL)."""
+    mode = "ok"
+    rank = 0
+    log: list = []
+
+    @staticmethod
+    def comm_available():
+        return "no librccl here" if _FakeRcclEngine.mode == "unavailable_on_1" and _FakeRcclEngine.rank == 1 else None
+
+    @staticmethod
+    def comm_unique_id():
+        if _FakeRcclEngine.mode == "id_fails":
+            raise RuntimeError("ncclGetUniqueId failed (injected)")
+        return b"x" * 128
+
+    def comm_init(self, rank, size, uid):
+        assert uid == b"x" * 128
+        if _FakeRcclEngine.mode == "init_fails_on_1" and rank == 1:
+            raise RuntimeError("ncclCommInitRank failed (injected)")
+        self.log.append("init")
+
+    def comm_destroy(self):
+        self.log.append("destroy")
+
+
+def _comm_setup_worker(rank, world, port, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    _FakeRcclEngine.mode, _FakeRcclEngine.rank, _FakeRcclEngine.log = mode, rank, []
+    eng = _FakeRcclEngine()
+    try:
+        pkg.parallel.RcclComm(eng, dist, fail_on_ranks=(0,) if mode == "forced_on_0" else ())
+        q.put((rank, "ok", list(eng.log)))
+    except RuntimeError as ex:
+        q.put((rank, "raised: " + str(ex), list(eng.log)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ok", "forced_on_0", "unavailable_on_1", "id_fails", "init_fails_on_1"])
+def test_rccl_comm_setup_is_collective(mode):
+    """Round-3 ADVICE: a failure on one rank only (rank 0 cannot obtain the id; one rank cannot load RCCL or fails in
+    c2r_comm_init) left the other ranks waiting inside a collective.  Now both ranks return within the time-out,
+    with the same verdict, and a rank whose own c2r_comm_init succeeded gives its communicator back."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_setup_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (verdict, log) for r, verdict, log in collect_from_ranks(procs, q, nresults=2, timeout=120)}
+    if mode == "ok":
+        assert got[0] == ("ok", ["init"]) and got[1] == ("ok", ["init"])
+    else:
+        assert got[0][0].startswith("raised") and got[1][0].startswith("raised"), got
+        if mode == "init_fails_on_1":
+            assert got[0][1] == ["init", "destroy"] and got[1][1] == []
+        else:
+            assert got[0][1] == [] and got[1][1] == []
