@@ -125,7 +125,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build()
+    # C2R_LIB_PATH: another build of this library (an A/B on one GPU box: tools/ab.sh); never a different product
+    import os
+    alt = os.environ.get("C2R_LIB_PATH")
+    path = Path(alt) if alt else _build.build()
     if not path.exists():
         raise C2RayHipError(f"{path} is missing and could not be built: the HIP extension is required")
     lib = C.CDLL(str(path))

@@ -533,6 +533,38 @@ C2R_HD double read_table(const double *col, const TauPos &p) {
   return a + (b - a) * p.residual;
 }
 
+// Heating tables as the rates kernels read them: INTERLEAVED by band.  The reference keeps one column of 0:NumTau
+// per (band, species) -- 1 + 2 x 26 + 3 x 20 = 113 columns (radiation_sizes.f90:23) -- and heat_lookuptable reads,
+// for a band with n absorbing species, n columns at the same one or two table positions: n (or 2n) gathers from
+// lines 16 KB apart.  Here the n columns of a band are woven together, entry (row r, species k) of band b at
+// first_col(b) * NTAUP + r * n + k: the values of one position are n neighbours, the two rows of an interpolation
+// 2n consecutive doubles -- one or two cache lines per position instead of n or 2n.  Same numbers, same
+// arithmetic (read_heat forms a + (b - a) * residual per species like read_table).  A band's block has the size
+// of its n columns, so the whole table keeps its size and every band its offset.  The duplicated last row
+// (NTAUP = NumTau + 2) is kept per species.
+C2R_HD int heat_species(int b) { return b < NB1 ? 1 : (b < NB1 + NB2 ? 2 : 3); }
+C2R_HD int heat_first_col(int b) { // 0-based heating column of (band b, HI)
+  return b < NB1 ? b : (b < NB1 + NB2 ? 2 * (b + 1) - NB1 - 2 : 3 * (b + 1) - NB2 - 2 * NB1 - 3);
+}
+// columns of pitch NTAUP -> interleaved (host side, once per table set)
+inline void heat_interleave(const double *cols, double *woven) {
+  for (int b = 0; b < NFREQ; b++) {
+    const int n = heat_species(b), c0 = heat_first_col(b);
+    for (int k = 0; k < n; k++)
+      for (int r = 0; r < NTAUP; r++) woven[(size_t)c0 * NTAUP + (size_t)r * n + k] = cols[(size_t)(c0 + k) * NTAUP + r];
+  }
+}
+// the N species of a band at one table position; `band` points at the band's block of an interleaved table
+template <int N>
+C2R_HD void read_heat(const double *band, const TauPos &p, double (&t)[N]) {
+  const double *e = band + (unsigned)p.ipos * (unsigned)N;
+  double lo[N], hi[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) { lo[k] = e[k]; hi[k] = e[N + k]; }
+#pragma unroll
+  for (int k = 0; k < N; k++) t[k] = lo[k] + (hi[k] - lo[k]) * p.residual;
+}
+
 // Beyond some optical depth the tables of a band hold exact zeros (the integrands of radiation_tables.f90:471
 // are cut at tau*s(nu) >= 700): every rate of the band is then +0, and adding it changes no sum.  In neutral gas
 // behind an ionisation front that is most bands of most cells.  Given the band's columns (pitch NTAUP, `ncols` of
@@ -560,6 +592,24 @@ struct PhotoOut {
 struct Ricotti {
   double y1R[3], y2R[3];
 };
+// The six numbers are used by the heating bands only, a few times per band; a kernel short of registers may keep them
+// somewhere cheaper than twelve vector registers for the whole of its source loop (k_rates: LDS, one column per lane):
+// RicottiParked points at y1R[0] of this lane, component n (y1R[0..2], y2R[0..2]) lies n * stride doubles further on.
+#if defined(__HIP_DEVICE_COMPILE__)
+// LDS, said so in the type: a volatile access through a generic pointer is a flat_load with system scope
+typedef const volatile __attribute__((address_space(3))) double *ParkedPtr;
+#else
+typedef const volatile double *ParkedPtr;
+#endif
+struct RicottiParked {
+  ParkedPtr p;
+  int stride;
+};
+C2R_HD double ric_y1(const Ricotti &r, int i) { return r.y1R[i]; }
+C2R_HD double ric_y2(const Ricotti &r, int i) { return r.y2R[i]; }
+// (volatile: read where it is used -- hoisted out of the band loops the values would be back in registers)
+C2R_HD double ric_y1(const RicottiParked &r, int i) { return r.p[i * r.stride]; }
+C2R_HD double ric_y2(const RicottiParked &r, int i) { return r.p[(3 + i) * r.stride]; }
 C2R_HD Ricotti ricotti_parameters(double i_state) {
   const double CR1[3] = {0.3908, 0.0554, 1.0}, bR1[3] = {0.4092, 0.4614, 0.2663},
                dR1[3] = {1.7592, 1.6660, 1.3163};
@@ -646,9 +696,9 @@ struct BandShared {
   TauPos pin, pout;
   double sc_HI, sc_HeI, sc_HeII;
 };
-template <bool HEAT, int CLS>
+template <bool HEAT, int CLS, class RIC>
 C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
-                     const double *heat_thin, int b, const CellSrc &c, double NFlux, const BandShared &B, const Ricotti &ric,
+                     const double *heat_thin, int b, const CellSrc &c, double NFlux, const BandShared &B, const RIC &ric,
                      SedSums &o) {
   const double sHI = B.sHI, sHeI = B.sHeI, sHeII = B.sHeII, dtau = B.dtau;
   const bool thick = B.thick, hthick = B.hthick;
@@ -693,8 +743,8 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
   }
 
   if (HEAT) {
-    const double *y1R = ric.y1R, *y2R = ric.y2R;
     double df_heat;
+    // heat_thick / heat_thin: interleaved tables (heat_interleave)
     if (CLS == 0) {
       const double *tk = heat_thick + (size_t)b * NTAUP;
       double a[1];
@@ -709,19 +759,20 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
       df_heat = h[0];
     } else if (CLS == 1) {
       const int cH = 2 * (b + 1) - NB1 - 1 - 1; // 0-based heating column of (band, HI)
-      const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP;
       double a[2];
       if (hthick) {
-        const double t0 = read_table(tkH, pin), t1 = read_table(tkHe, pin);
-        const double u0 = read_table(tkH, pout), u1 = read_table(tkHe, pout);
-        const double in_HI = NFlux * t0, in_HeI = NFlux * t1;
-        const double out_HI = NFlux * u0, out_HeI = NFlux * u1;
+        double t[2], u[2];
+        read_heat<2>(heat_thick + (size_t)cH * NTAUP, pin, t);
+        read_heat<2>(heat_thick + (size_t)cH * NTAUP, pout, u);
+        const double in_HI = NFlux * t[0], in_HeI = NFlux * t[1];
+        const double out_HI = NFlux * u[0], out_HeI = NFlux * u[1];
         a[0] = sc_HI * (in_HI - out_HI);
         a[1] = sc_HeI * (in_HeI - out_HeI);
       } else {
-        const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP;
-        a[0] = NFlux * (c.cell_HI * sHI) * read_table(tnH, pin);
-        a[1] = NFlux * (c.cell_HeI * sHeI) * read_table(tnHe, pin);
+        double t[2];
+        read_heat<2>(heat_thin + (size_t)cH * NTAUP, pin, t);
+        a[0] = NFlux * (c.cell_HI * sHI) * t[0];
+        a[1] = NFlux * (c.cell_HeI * sHeI) * t[1];
       }
       double h[2];
       div_by_vol<2>(c.rvol, a, h);
@@ -732,26 +783,27 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
       const double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
       const double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
       const double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
-      o.df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
-      o.df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
-      df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+      o.df_ion_HeI = ric_y1(ric, 1) * fra_sum1 - ric_y2(ric, 1) * fra_sum2;
+      o.df_ion_HI = ric_y1(ric, 0) * fra_sum1 - ric_y2(ric, 0) * fra_sum2;
+      df_heat = df_heat - ric_y1(ric, 2) * fra_sum3 + ric_y2(ric, 2) * fra_sum4;
     } else {
       const int cH = 3 * (b + 1) - NB2 - NB1 * 2 - 2 - 1;
-      const double *tkH = heat_thick + (size_t)cH * NTAUP, *tkHe = tkH + NTAUP, *tkHe2 = tkHe + NTAUP;
       double a[3];
       if (hthick) {
-        const double t0 = read_table(tkH, pin), t1 = read_table(tkHe, pin), t2 = read_table(tkHe2, pin);
-        const double u0 = read_table(tkH, pout), u1 = read_table(tkHe, pout), u2 = read_table(tkHe2, pout);
-        const double in_HI = NFlux * t0, in_HeI = NFlux * t1, in_HeII = NFlux * t2;
-        const double out_HI = NFlux * u0, out_HeI = NFlux * u1, out_HeII = NFlux * u2;
+        double t[3], u[3];
+        read_heat<3>(heat_thick + (size_t)cH * NTAUP, pin, t);
+        read_heat<3>(heat_thick + (size_t)cH * NTAUP, pout, u);
+        const double in_HI = NFlux * t[0], in_HeI = NFlux * t[1], in_HeII = NFlux * t[2];
+        const double out_HI = NFlux * u[0], out_HeI = NFlux * u[1], out_HeII = NFlux * u[2];
         a[0] = sc_HI * (in_HI - out_HI);
         a[1] = sc_HeI * (in_HeI - out_HeI);
         a[2] = sc_HeII * (in_HeII - out_HeII);
       } else {
-        const double *tnH = heat_thin + (size_t)cH * NTAUP, *tnHe = tnH + NTAUP, *tnHe2 = tnHe + NTAUP;
-        a[0] = NFlux * (c.cell_HI * sHI) * read_table(tnH, pin);
-        a[1] = NFlux * (c.cell_HeI * sHeI) * read_table(tnHe, pin);
-        a[2] = NFlux * (c.cell_HeII * sHeII) * read_table(tnHe2, pin);
+        double t[3];
+        read_heat<3>(heat_thin + (size_t)cH * NTAUP, pin, t);
+        a[0] = NFlux * (c.cell_HI * sHI) * t[0];
+        a[1] = NFlux * (c.cell_HeI * sHeI) * t[1];
+        a[2] = NFlux * (c.cell_HeII * sHeII) * t[2];
       }
       double h[3];
       div_by_vol<3>(c.rvol, a, h);
@@ -762,9 +814,9 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
       const double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
       const double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
       const double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
-      o.df_ion_HeI = y1R[1] * fra_sum1 - y2R[1] * fra_sum2;
-      o.df_ion_HI = y1R[0] * fra_sum1 - y2R[0] * fra_sum2;
-      df_heat = df_heat - y1R[2] * fra_sum3 + y2R[2] * fra_sum4;
+      o.df_ion_HeI = ric_y1(ric, 1) * fra_sum1 - ric_y2(ric, 1) * fra_sum2;
+      o.df_ion_HI = ric_y1(ric, 0) * fra_sum1 - ric_y2(ric, 0) * fra_sum2;
+      df_heat = df_heat - ric_y1(ric, 2) * fra_sum3 + ric_y2(ric, 2) * fra_sum4;
     }
     o.f_heat = o.f_heat + df_heat;
     o.f_ion_HI = o.f_ion_HI + o.df_ion_HI;
@@ -828,10 +880,10 @@ C2R_HD void band_positions(const LT *logtab, const CellSrc &c, double tau_in, do
 // `look_for_zero`: test whether the band is beyond the last non-zero table entry (band_tau_zero); returns
 // whether it was.  Within a class the optical depth falls from band to band, so once no lane of a wave has
 // found a band dead the caller stops asking (a missed skip costs time, never a bit).
-template <bool HEAT, int CLS, class LT>
+template <bool HEAT, int CLS, class LT, class RIC>
 C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
                        const double *heat_thin, const LT *logtab, const double *tau_zero, bool look_for_zero, int b,
-                       const CellSrc &c, const Ricotti &ric, SedSums &o) {
+                       const CellSrc &c, const RIC &ric, SedSums &o) {
   BandShared B;
   double tau_in, tau_out;
   band_depths<CLS>(bd, b, c, B, tau_in, tau_out);
@@ -850,11 +902,11 @@ C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const doub
 // their band range): optical depths, logs, table positions and species split once, then each SED's look-ups and sums
 // exactly as band_rates makes them -- every sum sees the same operands in the same order.  dead[k]: band_rates' return
 // value for SED k.
-template <bool HEAT, int CLS, class LT>
+template <bool HEAT, int CLS, class LT, class RIC>
 C2R_HD void band_rates_pair(const BandData &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
                             const double *const (&heat_thick)[2], const double *const (&heat_thin)[2], const LT *logtab,
                             const double *const (&tau_zero)[2], const bool (&look_for_zero)[2], int b, const CellSrc &c,
-                            const double (&NFlux)[2], const Ricotti &ric, SedSums (&o)[2], bool (&dead)[2]) {
+                            const double (&NFlux)[2], const RIC &ric, SedSums (&o)[2], bool (&dead)[2]) {
   BandShared B;
   double tau_in, tau_out;
   band_depths<CLS>(bd, b, c, B, tau_in, tau_out);
@@ -881,11 +933,11 @@ struct SedAcc {
 // heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands
 // [blo, bhi) (0-based), in three stretches by band class; every sum runs in band order as in the reference.
 // HEAT selects the non-isothermal path.  `logtab`: see tau_table_position.
-template <bool HEAT, class LT>
+template <bool HEAT, class LT, class RIC>
 C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                       const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
                       double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                      double NFlux, const Ricotti &ric, SedAcc &out, const LT *logtab, const double *tau_zero,
+                      double NFlux, const RIC &ric, SedAcc &out, const LT *logtab, const double *tau_zero,
                       const gm::LogPins *pins = nullptr) {
   out.photo_HI = out.photo_HeI = out.photo_HeII = 0.0;
   out.photo_out = 0.0;
@@ -936,11 +988,11 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
 
 // sed_rates for two SEDs with the same band range at once (band_rates_pair): out[k] is bit for bit what
 // sed_rates(tables of k, NFlux[k]) returns
-template <bool HEAT, class LT>
+template <bool HEAT, class LT, class RIC>
 C2R_HD void sed_rates_pair(const BandData &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
                            const double *const (&heat_thick)[2], const double *const (&heat_thin)[2], int blo, int bhi,
                            double cin_HI, double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII,
-                           double vol, const double (&NFlux)[2], const Ricotti &ric, SedAcc (&out)[2], const LT *logtab,
+                           double vol, const double (&NFlux)[2], const RIC &ric, SedAcc (&out)[2], const LT *logtab,
                            const double *const (&tau_zero)[2], const gm::LogPins *pins = nullptr) {
   CellSrc c;
   c.cin_HI = cin_HI; c.cin_HeI = cin_HeI; c.cin_HeII = cin_HeII;
@@ -986,11 +1038,11 @@ C2R_HD void sed_rates_pair(const BandData &bd, const double *const (&photo_thick
 }
 
 // photoion_rates for a source with the black-body SED only
-template <bool HEAT, class LT = double>
+template <bool HEAT, class LT = double, class RIC = Ricotti>
 C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
                            const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
                            double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
-                           double NFlux, const Ricotti &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
+                           double NFlux, const RIC &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
                            const gm::LogPins *pins = nullptr) {
   SedAcc a;
   sed_rates<HEAT, LT>(bd, photo_thick, photo_thin, heat_thick, heat_thin, 0, bd.bb_upper, cin_HI, cout_HI, cin_HeI, cout_HeI,
@@ -1019,29 +1071,57 @@ struct SedSet {
   int lo[NSED], hi[NSED]; // 0-based first band, one past the last band; lo == hi: SED absent
 };
 
-template <bool HEAT, class LT = double>
+template <bool HEAT, class LT = double, class RIC = Ricotti>
 C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                                  double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
-                                 const Ricotti &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
+                                 const RIC &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
                                  const gm::LogPins *pins = nullptr) {
   o.photo_HI = o.photo_HeI = o.photo_HeII = 0.0;
   o.heat = 0.0;
   o.photo_out = 0.0;
   // one band loop per SED over its own band range, like the reference's lookuptable calls (BB 1..33, PL and QPL
-  // 38..47 in the nominal set-up)
-  SedAcc a[NSED];
-  bool act[NSED];
-  for (int s = 0; s < NSED; s++) act[s] = NFlux[s] > 0.0 && ss.hi[s] > ss.lo[s];
-  // the two extra SEDs over the same bands (the nominal set-up: both 38..47): one band loop for both (band_rates_pair)
-#if defined(C2R_NO_SED_PAIR) // diagnostic build: one band loop per SED, as before round 3
+  // 38..47 in the nominal set-up).  The per-SED results live in NAMED variables, and the SED number -- uniform over
+  // the wave -- only ever selects between them: an array indexed by the loop counter of a loop the compiler cannot
+  // unroll (its trip count depends on `pair`) is a private segment, i.e. scratch memory, on the device
+  // (rounds 1-3: 176-208 bytes per lane, a few scratch accesses per cell.source).
+  const bool act0 = NFlux[0] > 0.0 && ss.hi[0] > ss.lo[0], act1 = NFlux[1] > 0.0 && ss.hi[1] > ss.lo[1],
+             act2 = NFlux[2] > 0.0 && ss.hi[2] > ss.lo[2];
+  // the two extra SEDs over the same bands (the nominal set-up: both 38..47): one band loop for both (band_rates_pair).
+  // Isothermal kernels only (round 4): with heating the pair's second set of running sums costs the rates kernel its
+  // fourth wave per SIMD -- measured on one box, 256^3, 128 sources per pass: every source with three SEDs 866 (pair,
+  // 2 waves) / 905 (no pair, 2 waves) / 868 ms (no pair, 4 waves); a third of the sources with a power law and a fifth
+  // with a quasar component 378 / 372 / 358 ms.  -DC2R_SED_PAIR_HEAT=1 brings it back, -DC2R_NO_SED_PAIR switches
+  // the pair off everywhere (diagnostic builds).
+#if defined(C2R_NO_SED_PAIR)
   const bool pair = false;
 #else
-  const bool pair = act[1] && act[2] && ss.lo[1] == ss.lo[2] && ss.hi[1] == ss.hi[2];
+#if !defined(C2R_SED_PAIR_HEAT)
+#define C2R_SED_PAIR_HEAT 0
 #endif
-  for (int s = 0; s < (pair ? 1 : NSED); s++) {
-    if (act[s])
-      sed_rates<HEAT, LT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
-                          cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, NFlux[s], ric, a[s], logtab, bd.tau_zero[s], pins);
+  const bool pair = (!HEAT || C2R_SED_PAIR_HEAT) && act1 && act2 && ss.lo[1] == ss.lo[2] && ss.hi[1] == ss.hi[2];
+#endif
+  // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)] runs along with the loops: every sum still receives BB, PL, QPL in
+  // that order.  The heat_lookuptable results are added after ALL the photo terms (:247-271), so f_ion of each SED
+  // waits in f_HI* / f_HeI*; o.heat only ever receives f_heat, in SED order as well.
+  double f_HI0 = 0.0, f_HI1 = 0.0, f_HI2 = 0.0, f_HeI0 = 0.0, f_HeI1 = 0.0, f_HeI2 = 0.0;
+  const int nsingle = pair ? 1 : NSED;
+  for (int s = 0; s < nsingle; s++) {
+    const bool act = s == 0 ? act0 : (s == 1 ? act1 : act2);
+    if (!act) continue;
+    const double nf = s == 0 ? NFlux[0] : (s == 1 ? NFlux[1] : NFlux[2]);
+    SedAcc a;
+    sed_rates<HEAT, LT>(bd, ss.photo_thick[s], ss.photo_thin[s], ss.heat_thick[s], ss.heat_thin[s], ss.lo[s], ss.hi[s], cin_HI,
+                        cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, nf, ric, a, logtab, bd.tau_zero[s], pins);
+    o.photo_HI = o.photo_HI + a.photo_HI;
+    o.photo_HeI = o.photo_HeI + a.photo_HeI;
+    o.photo_HeII = o.photo_HeII + a.photo_HeII;
+    o.photo_out = o.photo_out + a.photo_out;
+    if (HEAT) {
+      o.heat = o.heat + a.f_heat;
+      if (s == 0) { f_HI0 = a.f_ion_HI; f_HeI0 = a.f_ion_HeI; }
+      else if (s == 1) { f_HI1 = a.f_ion_HI; f_HeI1 = a.f_ion_HeI; }
+      else { f_HI2 = a.f_ion_HI; f_HeI2 = a.f_ion_HeI; }
+    }
   }
   if (pair) {
     const double *const pt[2] = {ss.photo_thick[1], ss.photo_thick[2]}, *const pn[2] = {ss.photo_thin[1], ss.photo_thin[2]};
@@ -1051,23 +1131,32 @@ C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double ci
     SedAcc a2[2];
     sed_rates_pair<HEAT, LT>(bd, pt, pn, ht, hn, ss.lo[1], ss.hi[1], cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol, nf,
                              ric, a2, logtab, tz, pins);
-    a[1] = a2[0];
-    a[2] = a2[1];
-  }
-  // phi = phi + photo_lookuptable(B) [+ (P)] [+ (Q)], then phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)]
-  for (int s = 0; s < NSED; s++) {
-    if (!act[s]) continue;
-    o.photo_HI = o.photo_HI + a[s].photo_HI;
-    o.photo_HeI = o.photo_HeI + a[s].photo_HeI;
-    o.photo_HeII = o.photo_HeII + a[s].photo_HeII;
-    o.photo_out = o.photo_out + a[s].photo_out;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      o.photo_HI = o.photo_HI + a2[k].photo_HI;
+      o.photo_HeI = o.photo_HeI + a2[k].photo_HeI;
+      o.photo_HeII = o.photo_HeII + a2[k].photo_HeII;
+      o.photo_out = o.photo_out + a2[k].photo_out;
+      if (HEAT) o.heat = o.heat + a2[k].f_heat;
+    }
+    if (HEAT) {
+      f_HI1 = a2[0].f_ion_HI; f_HeI1 = a2[0].f_ion_HeI;
+      f_HI2 = a2[1].f_ion_HI; f_HeI2 = a2[1].f_ion_HeI;
+    }
   }
   if (HEAT) {
-    for (int s = 0; s < NSED; s++) {
-      if (!act[s]) continue;
-      o.heat = o.heat + a[s].f_heat;
-      o.photo_HI = o.photo_HI + a[s].f_ion_HI / (ion_freq_HI * hplanck);
-      o.photo_HeI = o.photo_HeI + a[s].f_ion_HeI / (ion_freq_HeI * hplanck);
+    // phi = phi + heat_lookuptable(B) [+ (P)] [+ (Q)] (:247-271): only for the SEDs that ran
+    if (act0) {
+      o.photo_HI = o.photo_HI + f_HI0 / (ion_freq_HI * hplanck);
+      o.photo_HeI = o.photo_HeI + f_HeI0 / (ion_freq_HeI * hplanck);
+    }
+    if (act1) {
+      o.photo_HI = o.photo_HI + f_HI1 / (ion_freq_HI * hplanck);
+      o.photo_HeI = o.photo_HeI + f_HeI1 / (ion_freq_HeI * hplanck);
+    }
+    if (act2) {
+      o.photo_HI = o.photo_HI + f_HI2 / (ion_freq_HI * hplanck);
+      o.photo_HeI = o.photo_HeI + f_HeI2 / (ion_freq_HeI * hplanck);
     }
   }
 }

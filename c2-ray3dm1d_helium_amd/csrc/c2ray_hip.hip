@@ -64,6 +64,8 @@ struct Box {
 
 struct StepScalars {
   double dr1, dr2, dr3, vol;
+  double cellvol;       // dr1 * dr2 * dr3 (vol_ph of a source's own cell, evolve_point.F90:203), formed on the host: a product of
+                        // uniform numbers has no scalar instruction, and hoisted out of k_rates' source loop it costs two vector registers
   double clumping;
   double temper_val;
   RecCoef rc;
@@ -680,15 +682,23 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
 // Waves per SIMD the register allocation aims at.  The kernel is bound by instruction issue at any of these
 // occupancies, so the setting only steers how many copies, spills and waits the compiler makes; measured per variant
 // (isothermal: 20.1 / 19.8 / 19.8 ms at 5 / 4 / 3 waves -- 91 registers either way, so five waves still run;
-// heating, one SED: 31.5 / 29.4 / 29.5 ms at 4 / 3 / 2 waves; heating, three SEDs: 443 / 466 / 425 ms).
+// heating, one SED: 31.5 / 29.4 / 29.5 ms at 4 / 3 / 2 waves; heating, three SEDs: 443 / 466 / 425 ms in round 3, when
+// the kernel still kept its per-SED results in scratch memory; round 4, without scratch and without the SED pair:
+// 4 waves -- 128 registers, 4 of them spilled -- 358 against 372 ms at 2 waves, see photoion_rates_multi).
 #ifndef C2R_RATES_WAVES_HEAT
 #define C2R_RATES_WAVES_HEAT 3
 #endif
 #ifndef C2R_RATES_WAVES_HEAT_MULTI
-#define C2R_RATES_WAVES_HEAT_MULTI 2
+#define C2R_RATES_WAVES_HEAT_MULTI 4
 #endif
 #ifndef C2R_RATES_XCD_CHUNK
 #define C2R_RATES_XCD_CHUNK 128
+#endif
+#ifndef C2R_RATES_PARK_RICOTTI
+#define C2R_RATES_PARK_RICOTTI 0
+#endif
+#ifndef C2R_RATES_PARK_SUMS
+#define C2R_RATES_PARK_SUMS 2
 #endif
 template <bool HEAT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? C2R_RATES_WAVES_HEAT_MULTI : 4) : (HEAT ? C2R_RATES_WAVES_HEAT : C2R_RATES_WAVES_ISO))
@@ -748,23 +758,67 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   const int w_ = threadIdx.x >> 6;
   const int i = bi * 8 + (w_ & 1) * 4 + (lane & 3), j = bj * 8 + (w_ >> 1) * 4 + ((lane >> 2) & 3), k = bk * 4 + (lane >> 4);
   if (i >= g.n1 || j >= g.n2 || k >= g.n3) return;
-  const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
-  const double nd = ndens[q];
-  const double h0 = dmax(xh_av[q], epsilon), h1 = dmax(xh_av[q + nc], epsilon);
-  const double he0 = dmax(xhe_av[q], epsilon), he1 = dmax(xhe_av[q + nc], epsilon);
-  // fresh: the first launch after set_rates_to_zero when the launch covers every cell -- the grids then need not
-  // be zeroed first (4 x 8 bytes per cell written and read again: 1.3 ms per iteration at 256^3); 0 + x == x
+  // The cell's own quantities are needed once per source, after its band loops: only what those divisions use stays
+  // in registers across the loops -- the three denominators h0 * nd * (1 - abu_he), ... (evaluated from the left, as
+  // evolve_point.F90:288-296 does per source), not the four factors, and not the cell number, which is formed again
+  // for the stores at the end.
+  double den_HI, den_HeI, den_HeII, h1;
   double a_HI = 0.0, a_HeI = 0.0, a_HeII = 0.0, a_heat = 0.0;
-  if (!fresh) {
-    a_HI = rates[q];
-    a_HeI = rates[q + nc];
-    a_HeII = rates[q + 2 * nc];
-    if (HEAT) a_heat = rates[q + 3 * nc];
+  {
+    const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+    const double nd = ndens[q];
+    const double h0 = dmax(xh_av[q], epsilon);
+    h1 = dmax(xh_av[q + nc], epsilon);
+    const double he0 = dmax(xhe_av[q], epsilon), he1 = dmax(xhe_av[q + nc], epsilon);
+    den_HI = h0 * nd * (1.0 - abu_he);
+    den_HeI = he0 * nd * abu_he;
+    den_HeII = he1 * nd * abu_he;
+    // fresh: the first launch after set_rates_to_zero when the launch covers every cell -- the grids then need not
+    // be zeroed first (4 x 8 bytes per cell written and read again: 1.3 ms per iteration at 256^3); 0 + x == x
+    if (!fresh) {
+      a_HI = rates[q];
+      a_HeI = rates[q + nc];
+      a_HeII = rates[q + 2 * nc];
+      if (HEAT) a_heat = rates[q + 3 * nc];
+    }
   }
   // secondary-ionisation parameters of this cell, i_state = h_av(1) (evolve_point.F90:255): once per cell,
   // not once per source
-  Ricotti ric = {};
-  if (HEAT) ric = ricotti_parameters(h1);
+  // Values of a cell that the band loops do not touch can wait in LDS, one column per lane, where the register
+  // allocation would otherwise spill them to scratch memory (bit 0 of the macros: the one-SED heating kernel, bit 1: the
+  // three-SED heating kernel).  C2R_RATES_PARK_SUMS: the cell's denominators and running sums, touched once per source
+  // (default: the three-SED kernel, which then fits four waves per SIMD without a private segment).
+  // C2R_RATES_PARK_RICOTTI: the secondary-ionisation parameters too (default: nowhere -- six LDS reads per heating band
+  // cost more than the registers: 369 against 357 ms per pass on one box).
+  constexpr bool PARK = HEAT && (((C2R_RATES_PARK_SUMS) >> (MULTI ? 1 : 0)) & 1) != 0;
+  constexpr bool PARK_RIC = HEAT && (((C2R_RATES_PARK_RICOTTI) >> (MULTI ? 1 : 0)) & 1) != 0;
+  __shared__ double s_ric[PARK_RIC ? 6 * BLOCK : 1];
+  // the three denominators of the cell and its four running sums, touched once per source: [den_HI, den_HeI, den_HeII,
+  // a_HI, a_HeI, a_HeII, a_heat] x BLOCK
+  __shared__ double s_den[PARK ? 7 * BLOCK : 1];
+  Ricotti ric_ = {};
+  if (HEAT) ric_ = ricotti_parameters(h1);
+  if (PARK_RIC) {
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+      s_ric[n * BLOCK + threadIdx.x] = ric_.y1R[n];
+      s_ric[(3 + n) * BLOCK + threadIdx.x] = ric_.y2R[n];
+    }
+  }
+  if (PARK) {
+    s_den[threadIdx.x] = den_HI;
+    s_den[BLOCK + threadIdx.x] = den_HeI;
+    s_den[2 * BLOCK + threadIdx.x] = den_HeII;
+    s_den[3 * BLOCK + threadIdx.x] = a_HI;
+    s_den[4 * BLOCK + threadIdx.x] = a_HeI;
+    s_den[5 * BLOCK + threadIdx.x] = a_HeII;
+    s_den[6 * BLOCK + threadIdx.x] = a_heat;
+  }
+  const RicottiParked ric_parked = {(ParkedPtr)&s_ric[PARK_RIC ? threadIdx.x : 0], BLOCK};
+  // (each lane reads back only what it wrote itself: no barrier)
+  const auto &ric = [&]() -> const std::conditional_t<PARK_RIC, RicottiParked, Ricotti> & {
+    if constexpr (PARK_RIC) return ric_parked; else return ric_;
+  }();
   bool touched = false;
   const int slot = tile_base + vb;
   const int e0 = tile_ptr ? tile_ptr[slot] : 0, e1 = tile_ptr ? tile_ptr[slot + 1] : nsrc;
@@ -790,7 +844,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     const double cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
     double vol_ph;
     if (di == 0 && dj == 0 && dk == 0) {
-      vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
+      vol_ph = sc.cellvol;
     } else {
       const double path = sc_path(di, dj, dk) * sc.dr1;
       const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
@@ -811,10 +865,18 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
           photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
                                cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, &s_logtab[0], pins);
         }
-        a_HI = a_HI + o.photo_HI / (h0 * nd * (1.0 - abu_he));
-        a_HeI = a_HeI + o.photo_HeI / (he0 * nd * abu_he);
-        a_HeII = a_HeII + o.photo_HeII / (he1 * nd * abu_he);
-        if (HEAT) a_heat = a_heat + o.heat;
+        if (PARK) { // (volatile: read here, not hoisted back into registers)
+          volatile __attribute__((address_space(3))) double *dn = (volatile __attribute__((address_space(3))) double *)&s_den[threadIdx.x];
+          dn[3 * BLOCK] = dn[3 * BLOCK] + o.photo_HI / dn[0];
+          dn[4 * BLOCK] = dn[4 * BLOCK] + o.photo_HeI / dn[BLOCK];
+          dn[5 * BLOCK] = dn[5 * BLOCK] + o.photo_HeII / dn[2 * BLOCK];
+          dn[6 * BLOCK] = dn[6 * BLOCK] + o.heat;
+        } else {
+          a_HI = a_HI + o.photo_HI / den_HI;
+          a_HeI = a_HeI + o.photo_HeI / den_HeI;
+          a_HeII = a_HeII + o.photo_HeII / den_HeII;
+          if (HEAT) a_heat = a_heat + o.heat;
+        }
         if (decltype(with_loss)::value) photo_out = o.photo_out;
       } else {
         // rates are zero: x + 0.0 == x
@@ -844,6 +906,13 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     }
   }
   if (touched || fresh) {
+    const size_t q = (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
+    if (PARK) {
+      a_HI = s_den[3 * BLOCK + threadIdx.x];
+      a_HeI = s_den[4 * BLOCK + threadIdx.x];
+      a_HeII = s_den[5 * BLOCK + threadIdx.x];
+      a_heat = s_den[6 * BLOCK + threadIdx.x];
+    }
     rates[q] = a_HI;
     rates[q + nc] = a_HeI;
     rates[q + 2 * nc] = a_HeII;
@@ -1409,6 +1478,9 @@ struct c2r_ctx {
   std::string err;
 
   double *d_photo_thick = nullptr, *d_photo_thin = nullptr, *d_heat_thick = nullptr, *d_heat_thin = nullptr;
+  // the heating tables as the kernels read them, interleaved by band (c2ray_device.hpp heat_interleave): [sed][thick, thin];
+  // the column-wise copies above (and d_sed_tab[][2..3]) stay for c2r_download_tables and band_tau_zero
+  double *d_heat_woven[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   BandData *d_bands = nullptr;
   BandData h_bands{};              // host copy (tau_zero is refreshed whenever a table set changes)
   bool have_tables = false, have_heat_tables = false, have_bands = false, have_fvec = false;
@@ -1809,6 +1881,9 @@ extern "C" void c2r_destroy(c2r_ctx *c) {
                   c->d_rates_own, c->d_stateT, c->d_loss_partial, c->d_loss_acc, c->d_conv, c->d_colgrid, c->d_rc_last, c->d_stat, c->d_lls, c->d_clump, c->d_block_base, c->d_defer[0], c->d_defer[1], c->d_chemctl, c->d_chemspread};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto &w : c->d_heat_woven)
+    for (double *p : w)
+      if (p) (void)hipFree(p);
   for (auto &list : c->segs)
     for (auto &sg : list)
       if (sg.p) (void)hipFree(sg.p);
@@ -1903,6 +1978,14 @@ static int refresh_tau_zero(c2r_ctx *c, int sed) {
         }
       }
       c->h_bands.tau_zero[sed][b] = band_tau_zero(cols, n);
+    }
+    if (heat) { // the copies the kernels read (same numbers, woven by band)
+      std::vector<double> woven((size_t)NHEAT * NTAUP);
+      for (int t = 0; t < 2; t++) {
+        heat_interleave(h[2 + t].data(), woven.data());
+        if (!c->d_heat_woven[sed][t]) HIPCHK(c, hipMalloc(&c->d_heat_woven[sed][t], sizeof(double) * woven.size()));
+        HIPCHK(c, hipMemcpy(c->d_heat_woven[sed][t], woven.data(), sizeof(double) * woven.size(), hipMemcpyHostToDevice));
+      }
     }
   }
   if (c->have_bands) HIPCHK(c, hipMemcpy(c->d_bands, &c->h_bands, sizeof(BandData), hipMemcpyHostToDevice));
@@ -2235,15 +2318,17 @@ static SedSet sedset(c2r_ctx *c, bool *multi) {
   const BandData *unused = nullptr;
   (void)unused;
   ss.photo_thick[0] = c->d_photo_thick; ss.photo_thin[0] = c->d_photo_thin;
-  ss.heat_thick[0] = c->d_heat_thick;   ss.heat_thin[0] = c->d_heat_thin;
+  // heating tables: the interleaved copies (made with tau_zero whenever a SED's tables are set or built)
+  ss.heat_thick[0] = c->have_heat_tables ? c->d_heat_woven[0][0] : nullptr;
+  ss.heat_thin[0] = c->have_heat_tables ? c->d_heat_woven[0][1] : nullptr;
   ss.lo[0] = 0; ss.hi[0] = c->bb_upper;
   *multi = false;
   for (int k = 0; k < 2; k++) {
     const bool on = c->have_sed[k] && !c->normflux_sed[k].empty();
     ss.photo_thick[k + 1] = on ? c->d_sed_tab[k][0] : nullptr;
     ss.photo_thin[k + 1] = on ? c->d_sed_tab[k][1] : nullptr;
-    ss.heat_thick[k + 1] = on ? c->d_sed_tab[k][2] : nullptr;
-    ss.heat_thin[k + 1] = on ? c->d_sed_tab[k][3] : nullptr;
+    ss.heat_thick[k + 1] = on && c->have_sed_heat[k] ? c->d_heat_woven[k + 1][0] : nullptr;
+    ss.heat_thin[k + 1] = on && c->have_sed_heat[k] ? c->d_heat_woven[k + 1][1] : nullptr;
     ss.lo[k + 1] = on ? c->sed_lo[k] : 0;
     ss.hi[k + 1] = on ? c->sed_hi[k] : 0;
     *multi = *multi || on;
@@ -2253,6 +2338,7 @@ static SedSet sedset(c2r_ctx *c, bool *multi) {
 
 static StepScalars scalars(c2r_ctx *c) {
   StepScalars s = c->sc;
+  s.cellvol = s.dr1 * s.dr2 * s.dr3;
   s.cd.cool = c->d_cool;
   s.cd.mintemp = c->cool_mintemp;
   s.cd.dtemp = c->cool_dtemp;

@@ -16,6 +16,7 @@ namespace {
 struct Tables {
   BandData bd;
   std::vector<double> pthick, pthin, hthick, hthin, cool;
+  std::vector<double> hthick_il, hthin_il; // as the product's kernels read them (heat_interleave)
   double mintemp, dtemp;
 };
 Tables T;
@@ -64,6 +65,10 @@ void hh_set_tables(const double *pthick, const double *pthin, const double *hthi
   for (int i = 0; i < 12; i++) std::memcpy(dst[i], f[i], sizeof(double) * (NFREQ - 1));
   T.bd.bb_upper = bb_upper;
   set_tau_zero(0, T.pthick, T.pthin, T.hthick, T.hthin);
+  T.hthick_il.resize(T.hthick.size());
+  T.hthin_il.resize(T.hthin.size());
+  heat_interleave(T.hthick.data(), T.hthick_il.data());
+  heat_interleave(T.hthin.data(), T.hthin_il.data());
   for (int s = 1; s < 3; s++)
     for (int b = 0; b < NFREQ; b++) T.bd.tau_zero[s][b] = (double)INFINITY;
   T.cool.assign(cool, cool + 5 * NCOOL);
@@ -83,7 +88,7 @@ void hh_photoion(const double *cin6, double vol, double nflux, double i_state, i
   Ricotti ric = {};
   if (heat) ric = ricotti_parameters(i_state);
   if (heat)
-    photoion_rates<true>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick.data(), T.hthin.data(), cin6[0], cin6[1],
+    photoion_rates<true>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick_il.data(), T.hthin_il.data(), cin6[0], cin6[1],
                          cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux, ric, o);
   else
     photoion_rates<false>(T.bd, T.pthick.data(), T.pthin.data(), T.hthick.data(), T.hthin.data(), cin6[0], cin6[1],
@@ -93,7 +98,7 @@ void hh_photoion(const double *cin6, double vol, double nflux, double i_state, i
 
 // the three-SED variant: tables of SED 1 (pl) and 2 (qpl) in the same layout as the BB ones
 namespace {
-std::vector<double> S_pt[2], S_pn[2], S_ht[2], S_hn[2];
+std::vector<double> S_pt[2], S_pn[2], S_ht[2], S_hn[2], S_ht_il[2], S_hn_il[2];
 int S_lo[2] = {0, 0}, S_hi[2] = {0, 0};
 }
 void hh_set_sed(int sed, const double *pthick, const double *pthin, const double *hthick, const double *hthin, int lower,
@@ -106,15 +111,19 @@ void hh_set_sed(int sed, const double *pthick, const double *pthin, const double
   S_lo[k] = lower - 1;
   S_hi[k] = upper;
   set_tau_zero(sed, S_pt[k], S_pn[k], S_ht[k], S_hn[k]);
+  S_ht_il[k].resize(S_ht[k].size());
+  S_hn_il[k].resize(S_hn[k].size());
+  heat_interleave(S_ht[k].data(), S_ht_il[k].data());
+  heat_interleave(S_hn[k].data(), S_hn_il[k].data());
 }
 static SedSet make_sedset() {
   SedSet ss;
   ss.photo_thick[0] = T.pthick.data(); ss.photo_thin[0] = T.pthin.data();
-  ss.heat_thick[0] = T.hthick.data(); ss.heat_thin[0] = T.hthin.data();
+  ss.heat_thick[0] = T.hthick_il.data(); ss.heat_thin[0] = T.hthin_il.data();
   ss.lo[0] = 0; ss.hi[0] = T.bd.bb_upper;
   for (int k = 0; k < 2; k++) {
     ss.photo_thick[k + 1] = S_pt[k].data(); ss.photo_thin[k + 1] = S_pn[k].data();
-    ss.heat_thick[k + 1] = S_ht[k].data(); ss.heat_thin[k + 1] = S_hn[k].data();
+    ss.heat_thick[k + 1] = S_ht_il[k].data(); ss.heat_thin[k + 1] = S_hn_il[k].data();
     ss.lo[k + 1] = S_lo[k]; ss.hi[k + 1] = S_hi[k];
   }
   return ss;

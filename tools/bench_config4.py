@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--heating", action="store_true")
     ap.add_argument("--config5", action="store_true")
     ap.add_argument("--pl", action="store_true", help="the SEDs, heating and device-built tables of --config5 at --mesh / --sources")
+    ap.add_argument("--all-seds", action="store_true", help="with --pl / --config5: EVERY source has a power-law and a quasar-like component")
     ap.add_argument("--correlated", type=float, default=0.0, metavar="INDEX",
                     help="log-density with power spectrum k^-INDEX (e.g. 2.5) instead of white noise: neighbouring cells alike")
     ap.add_argument("--headline", action="store_true", help="bench.py's workload instead (256^3, 8 bright sources, pre-ionised gas): for --lane-census")
@@ -124,8 +125,8 @@ def main():
             tables.setup = {k: z[k] for k in z.files}
         tables.build_on_device = True
         idx = np.arange(a.sources)
-        src.NormFluxPL = np.where(idx % 3 == 0, 0.3 * src.NormFlux, 0.0)
-        src.NormFluxQPL = np.where(idx % 5 == 0, 0.5 * src.NormFlux, 0.0)
+        src.NormFluxPL = np.where((idx % 3 == 0) | a.all_seds, 0.3 * src.NormFlux, 0.0)
+        src.NormFluxQPL = np.where((idx % 5 == 0) | a.all_seds, 0.5 * src.NormFlux, 0.0)
     e = pkg.HipEngine((n, n, n), 0)
     t_tab = time.perf_counter()
     e.set_tables(tables)
