@@ -2096,8 +2096,16 @@ static int set_sources_one(c2r_ctx *c, int nsrc, const int *srcpos, const double
     if (p[0] < 1 || p[0] > c->g.n1 || p[1] < 1 || p[1] > c->g.n2 || p[2] < 1 || p[2] > c->g.n3)
       return fail(c, "c2r_set_sources: source %d at (%d,%d,%d) outside the mesh", s + 1, p[0], p[1], p[2]);
   }
+  // What the last pass learnt about each source -- how many sub-boxes it needed: the size of its column block and the
+  // rounds that are swept without waiting for a loss probe -- stays valid across time steps as long as the source list
+  // is the same (the reference's driver passes the same list at every evolve3D call of a redshift slice); a wrong
+  // guess costs time, never a bit.  Forgetting it made every evolve3D call after the first regrow its column blocks
+  // and probe every round again: 2.7 ms per iteration over the 8-9 iterations of such a call (round 3's
+  // dropin timing: 26.0 against 23.1 ms).
+  const bool same_list = nsrc == c->nsrc && c->srcpos.size() == 3 * (size_t)nsrc &&
+                         std::equal(srcpos, srcpos + 3 * (size_t)nsrc, c->srcpos.begin());
   c->nsrc = nsrc;
-  c->prev_nbox.assign((size_t)nsrc, 0);
+  if (!same_list || c->prev_nbox.size() != (size_t)nsrc) c->prev_nbox.assign((size_t)nsrc, 0);
   c->srcpos.assign(srcpos, srcpos + 3 * (size_t)nsrc);
   c->normflux.assign(normflux, normflux + nsrc);
   c->s_star = s_star;

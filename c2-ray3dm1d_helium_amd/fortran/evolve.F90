@@ -110,8 +110,9 @@ contains
     integer :: niter
     integer :: conv_flag
     integer :: conv_criterion
-    integer(kind=8) :: wallclock1, wallclock2, countspersec
-    integer(kind=8) :: loopclock1, loopclock2
+    integer(kind=8) :: wallclock0, wallclock1, wallclock2, countspersec
+    integer(kind=8) :: loopclock1, loopclock2, callclock2
+    type(c2r_timing) :: kernel_times
     logical :: dump_due, fused
     integer(c_int) :: iso
     real(kind=dp) :: reccoef(12)
@@ -119,6 +120,7 @@ contains
     type(c_ptr) :: tptr
 
     call system_clock (wallclock1)
+    wallclock0 = wallclock1
 
     if (.not. tables_uploaded) call upload_tables ()
     if (.not. fused_settings_read) call read_fused_settings ()
@@ -219,6 +221,11 @@ contains
 
        if (rank == 0) write(timefile,"(A,I3,A,F8.1)") &
             "Time after iteration ",niter," : ", timestamp_wallclock ()
+       if (rank == 0 .and. loop_timing) then
+          call check (c2r_get_timing (hip_ctx, kernel_times), "c2r_get_timing")
+          write(timefile,"(A,I4,3(A,F9.3),A)") "evolve3D kernels, iteration ",niter,": sweep ",kernel_times%sweep_ms, &
+               " ms, rates ",kernel_times%rates_ms," ms, chemistry ",kernel_times%chem_ms," ms"
+       endif
     enddo
 
     ! C2RAY_HIP_TIMING=1: the loop's wall time with the clock's own resolution (Timings.log has tenths of a second)
@@ -235,6 +242,13 @@ contains
     call photon_statistics (dt,n_after)
     call report_photonstatistics (dt)
     call update_grandtotal_photonstatistics (dt)
+
+    ! ... and where a call's time goes besides the loop: host arrays to the device before it, results back after it
+    call system_clock (callclock2)
+    if (rank == 0 .and. loop_timing) write(timefile,"(A,3(F10.6,A))") "evolve3D call: set-up ", &
+         real(loopclock1-wallclock0,dp)/real(countspersec,dp), " s, loop ", &
+         real(loopclock2-loopclock1,dp)/real(countspersec,dp), " s, results ", &
+         real(callclock2-loopclock2,dp)/real(countspersec,dp), " s"
 
   end subroutine evolve3D
 
@@ -489,6 +503,8 @@ contains
     if (status == 0 .and. length > 0) then
        if (text(1:1) /= "0") loop_timing = .true.
     endif
+    ! with the loop's clock also the kernels of every iteration (HIP events on the library's streams)
+    if (loop_timing) call check (c2r_enable_timing (hip_ctx, 1_c_int), "c2r_enable_timing")
     call get_environment_variable ("C2R_ALLREDUCE_SLABS", text, length, status)
     if (status == 0 .and. length > 0) then
        read(text(1:length),*,iostat=status) n

@@ -65,6 +65,24 @@ def main():
         if m:
             calls.append({"iterations": int(m.group(1)), "seconds": float(m.group(2)),
                           "ms_per_iteration": 1e3 * float(m.group(2)) / int(m.group(1))})
+    parts = re.findall(r"evolve3D call: set-up\s*([\d.]+)\s*s, loop\s*([\d.]+)\s*s, results\s*([\d.]+)\s*s",
+                       (run / "results" / "Timings.log").read_text(errors="replace"))
+    for c, (a_, b_, c_) in zip(calls, parts):
+        c.update(setup_s=float(a_), results_s=float(c_), call_s=float(a_) + float(b_) + float(c_),
+                 ms_per_iteration_whole_call=1e3 * (float(a_) + float(b_) + float(c_)) / c["iterations"])
+    # kernels of every iteration, call by call (an iteration count that starts again at 1 opens a new call)
+    kern = re.findall(r"evolve3D kernels, iteration\s*(\d+): sweep\s*([\d.]+) ms, rates\s*([\d.]+) ms, chemistry\s*([\d.]+) ms",
+                      (run / "results" / "Timings.log").read_text(errors="replace"))
+    percall = []
+    for it, sw, ra, ch in kern:
+        if int(it) == 1:
+            percall.append([])
+        percall[-1].append((float(sw), float(ra), float(ch)))
+    for c, rows in zip(calls, percall):
+        c["kernel_ms_mean"] = {"sweep": sum(r[0] for r in rows) / len(rows), "rates": sum(r[1] for r in rows) / len(rows),
+                               "chemistry": sum(r[2] for r in rows) / len(rows)}
+        c["chemistry_ms_by_iteration"] = [r[2] for r in rows]
+        c["sweep_ms_by_iteration"] = [r[0] for r in rows]
     if not calls:
         raise SystemExit("no 'evolve3D loop' line in Timings.log")
     out = {"binary": str(exe.relative_to(ROOT)), "mode": "stepwise" if a.stepwise else "c2r_iteration", "driver_wall_s": wall,
