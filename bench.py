@@ -47,9 +47,32 @@ COLUMN_BYTES_PER_CELL_SOURCE = 88.0   # column sweep alone: 40 B state + 48 B co
 CHEM_BYTES_PER_CELL = 252.0           # SURVEY.md section 8(d), isothermal chemistry pass
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6               # MI355X_MICROARCH.md: 16 384 FP64 lanes x 2.4 GHz x 2 (vector; the matrix peak is the same)
-PMC_SUMMARY = next((p for p in (ROOT / "profiles" / f"r{r:02d}_bench_pmc_summary.json" for r in (3, 2)) if p.exists()),
-                   ROOT / "profiles" / "r03_bench_pmc_summary.json")
-DROPIN_TIMING = ROOT / "profiles" / "r03_dropin_timing.json"
+PMC_SUMMARY = ROOT / "profiles" / "r04_bench_pmc_summary.json"
+DROPIN_TIMING = ROOT / "profiles" / "r04_dropin_timing.json"
+REFERENCE_AT_SIZE = ROOT / "profiles" / "r04_reference_256.json"
+
+
+def kernel_source_sha16():
+    """First 16 hex digits of the SHA-256 over the library's sources (csrc/ and the C ABI header): what ties a stored
+    profile to the build it was taken from.  tools/pmc_summary.py and tools/time_dropin.py write the same figure into their
+    JSONs; a stored number is only quoted in the result line when it comes from the sources that are being timed."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted((ROOT / "c2-ray3dm1d_helium_amd" / "csrc").glob("*")) + [ROOT / "include" / "c2ray_hip.h"]
+    for f in files:
+        if f.suffix in (".hip", ".hpp", ".inc", ".h"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def stored_profile(path):
+    """(dict, same_build) of a stored JSON of profiles/, or (None, False)."""
+    try:
+        d = json.loads(path.read_text())
+    except Exception:
+        return None, False
+    return d, d.get("source_sha16") == kernel_source_sha16()
 
 
 def rates_bytes_per_launch(cells, nsrc, heating=False):
@@ -60,10 +83,14 @@ def rates_bytes_per_launch(cells, nsrc, heating=False):
 
 
 def stored_counter(kernel, counter):
-    """A per-launch counter of the committed rocprofv3 --pmc passes of this same command (tools/pmc_summary.py),
-    or None.  Stored, not measured in this run: the keys that use it say so."""
+    """A per-launch counter of the committed rocprofv3 --pmc passes of this same command (tools/pmc_summary.py), or None
+    -- also None when the profile was taken from other sources than the ones being timed.  Stored, not measured in this
+    run: the keys that use it say so, and `stored_profiles` in the result line names file and source hash."""
+    d, same = stored_profile(PMC_SUMMARY)
+    if d is None or not same:
+        return None
     try:
-        v = json.loads(PMC_SUMMARY.read_text())[kernel][counter]
+        v = d[kernel][counter]
         return v["per_launch"] if isinstance(v, dict) else v
     except Exception:
         return None
@@ -447,16 +474,31 @@ def main():
             # host time); in a one-process run every device shares the one wall clock
             out["per_rank_ms_per_step"] = [1e3 * r["elapsed"] / a.steps for r in allr]
             out["per_rank_kernel_ms_per_step"] = [(r["sweep_ms"] + r["rates_ms"]) / a.steps for r in allr]   # pass only (see above)
-        if headline and DROPIN_TIMING.exists():
+        if headline:
+            # what is quoted from profiles/ rather than measured in this run, and whether it was taken from these very sources
+            sha = kernel_source_sha16()
+            out["stored_profiles"] = {"running_source_sha16": sha}
+            for key, path in (("pmc", PMC_SUMMARY), ("dropin", DROPIN_TIMING), ("reference_at_size", REFERENCE_AT_SIZE)):
+                d, same = stored_profile(path)
+                if d is not None:
+                    out["stored_profiles"][key] = {"file": str(path.relative_to(ROOT)), "source_sha16": d.get("source_sha16"),
+                                                   "same_sources_as_this_run": same}
             # the product the north star describes -- the reference's Fortran driver with this library's modules linked
-            # in (oracle/ref_build.sh 256 hip) -- on this very workload, from the reference's own Timings.log stamps
-            # (evolve.F90:150,220); measured by tools/time_dropin.sh on a GPU box and stored (the driver's bench box has
-            # no reference sources to build the binary from)
-            try:
-                dj = json.loads(DROPIN_TIMING.read_text())
-                out["dropin_ms_per_iteration"] = {k: dj[k] for k in ("ms_per_iteration", "iterations", "bench_ms_per_step_same_box", "note") if k in dj}
-            except Exception:
-                pass
+            # in (oracle/ref_build.sh 256 hip) -- on this very workload, by the drop-in's own clock; measured by
+            # tools/time_dropin.py on a GPU box and stored (the driver's bench box has no reference sources to build the
+            # binary from); quoted only when taken from the sources being timed
+            dj, same = stored_profile(DROPIN_TIMING)
+            if dj is not None and same:
+                out["dropin_ms_per_iteration"] = {k: dj[k] for k in ("ms_per_iteration", "iterations", "bench_ms_per_step_same_box", "evolve3D_calls", "note") if k in dj}
+            # the reference's own OpenMP build on THIS workload's inputs at THIS size, timed in the dev container
+            # (tools/time_reference.py; the reference does not travel to the GPU box): stored and labelled so; it does not
+            # depend on this library's sources
+            rj, _ = stored_profile(REFERENCE_AT_SIZE)
+            if rj is not None:
+                out["cpu_baseline_reference_at_size"] = {
+                    "stored": str(REFERENCE_AT_SIZE.relative_to(ROOT)), "kind": "reference", "unit": "cell-updates/s", "cores": rj.get("threads"),
+                    "value": rj.get("cell_updates_per_s_at_mesh_limit"), "s_per_iteration": rj.get("s_per_iteration"),
+                    "sample": rj.get("what"), "how": rj.get("how"), "where": "dev container host cores, not the GPU box's"}
         if not a.no_cpu_baseline and world == 1 and not cfg4:
             out["cpu_baseline"] = cpu_baseline(pkg)
             ref = cpu_baseline_reference()

@@ -45,7 +45,14 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             # C2R_EXTRA_HIPCC_FLAGS: extra compiler flags for experiments
             extra = os.environ.get("C2R_EXTRA_HIPCC_FLAGS", "").split()
             tmp = LIB.with_name(f"{LIB.name}.tmp{os.getpid()}")
-            cmd = [hipcc(), *HIPCC_FLAGS, *extra, "-o", str(tmp), *map(str, SOURCES)]
+            cc = hipcc()
+            # build-time requirement besides hipcc itself: the RCCL header (csrc/c2ray_comm.inc binds librccl through its
+            # declarations; the library is loaded at run time, on first use of a communicator)
+            rocm = Path(cc).resolve().parent.parent
+            if not any((d / "rccl" / "rccl.h").exists() for d in (rocm / "include", Path("/opt/rocm/include"))):
+                raise RuntimeError(f"<rccl/rccl.h> not found under {rocm / 'include'} or /opt/rocm/include: install the RCCL "
+                                   "development files (part of ROCm); they are needed to BUILD libc2ray_hip even for single-GPU use")
+            cmd = [cc, *HIPCC_FLAGS, *extra, "-o", str(tmp), *map(str, SOURCES)]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 tmp.unlink(missing_ok=True)

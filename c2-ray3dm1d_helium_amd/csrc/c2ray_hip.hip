@@ -497,7 +497,8 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs &A, const SrcDev &S, 
 // constant, the path's division by s^2 as three fma, the 12 reciprocals of weightf without the division's operand
 // scaling, and the corners' positions from the face formulas of shell s-1 instead of four general inverse maps
 // (corners of weight exactly 0 on the edges of a face are read from the nearest cell of shell s-1).  Bit for bit
-// the columns of sweep_cell (tests: C2R_SWEEP_GENERIC=1 runs that one for every shell).
+// the columns of sweep_cell (tests/test_gpu_parity.py::test_fast_sweep_equals_the_general_sweep runs that one for every
+// shell, C2R_SWEEP_GENERIC=1, in a process of its own and compares the columns).
 __device__ __forceinline__ void sweep_cell_fast(const SweepArgs &A, const SrcDev &S, const ShellGeom &G, int t) {
   const Grid &g = A.g;
   const StepScalars &sc = A.sc;
@@ -1822,6 +1823,10 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipMalloc(&c->d_rates_own, sizeof(double) * c->rates_count));
   c->d_rates = c->d_rates_own;
   CR(zero_device(c->d_rates, sizeof(double) * c->rates_count, nullptr));
+  // the spread counters of the chemistry launches (CHEM_CTL_COPIES): here, not in the first global pass -- an allocation
+  // is a device-wide synchronisation, and an outer iteration has exactly one, at its end
+  CR(hipMalloc(&c->d_chemspread, sizeof(int) * (size_t)CHEM_CTL_COPIES * CHEM_CTL_STRIDE));
+  CR(hipMemset(c->d_chemspread, 0, sizeof(int) * (size_t)CHEM_CTL_COPIES * CHEM_CTL_STRIDE)); // k_chem_ctl_reduce leaves it zeroed
   CR(hipDeviceSynchronize()); // phih_grid = 0 for initial output (evolve_data.F90:77,80)
   // block bookkeeping of the shells 0..smax
   c->block_base.assign(c->g.smax + 2, 0);
@@ -2069,6 +2074,16 @@ static int set_cooling_one(c2r_ctx *c, const double *cool, double mintemp, doubl
   return 0;
 }
 
+// The lists of the heating tiers (cells dropped by a launch, redone by the next) and their counters: made when a step
+// is declared non-isothermal (c2r_set_step), zeroed on the stream their first user follows.
+static int alloc_heating_lists(c2r_ctx *c) {
+  if (c->isothermal || c->d_defer[0]) return 0;
+  for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
+  HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST))); // two list counts, then the histogram
+  HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST), c->stream));
+  return 0;
+}
+
 static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], double vol, float clumping,
                             double zred, double H0, double Omega0, int isothermal, double temper_val,
                             const double reccoef[12]) {
@@ -2076,6 +2091,8 @@ static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], dou
   if (!ndens || !dr || !reccoef) return fail(c, "c2r_set_step: null argument");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->d_ndens, ndens, sizeof(double) * c->g.ncell, hipMemcpyHostToDevice, c->stream));
+  c->isothermal = isothermal ? 1 : 0;
+  if (alloc_heating_lists(c)) return 1; // a non-isothermal step: the tiers' lists exist before any pass starts
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->sc.dr1 = dr[0]; c->sc.dr2 = dr[1]; c->sc.dr3 = dr[2]; c->sc.vol = vol;
   c->sc.clumping = (double)clumping;
@@ -2620,6 +2637,9 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   c->tm.sweep_launches = c->tm.rates_launches = 0;
   c->tm.cells_swept = 0;
   c->ev_used = 0;
+  // every pass is closed by pass_finish, which adds the batches' kept losses into photon_loss / sum_nbox and empties
+  // this list; entries still here belong to a pass that ended in an error and must not be added to this one
+  c->tails.clear();
   if (c->prev_nbox.size() != (size_t)c->nsrc) c->prev_nbox.assign((size_t)c->nsrc, 0);
   std::vector<hipEvent_t> tev; // per batch: sweep start, sweep end, rates start, rates end
   // a rank without sources writes nothing: a pending zeroing of the rate grids has to happen for real
@@ -3370,19 +3390,11 @@ static int fold_chemistry_counters(c2r_ctx *c, hipStream_t st) {
   return 0;
 }
 
+// Everything a global pass needs exists before it starts: the spread counters since c2r_create, the heating lists since
+// the c2r_set_step that declared the step non-isothermal (round 3 allocated both here, inside the first pass).
 static int ensure_chemistry_buffers(c2r_ctx *c) {
-  if (!c->d_chemspread) {
-    const size_t bytes = sizeof(int) * (size_t)CHEM_CTL_COPIES * CHEM_CTL_STRIDE;
-    HIPCHK(c, hipMalloc(&c->d_chemspread, bytes));
-    // (on the main stream, which the first launch follows -- or waits for through an event: a hipMemset on the null
-    // stream is not ordered with launches on non-blocking streams); k_chem_ctl_reduce leaves it zeroed every time
-    HIPCHK(c, hipMemsetAsync(c->d_chemspread, 0, bytes, c->stream));
-  }
-  if (!c->isothermal && !c->d_defer[0]) {
-    for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
-    HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST))); // two list counts, then the histogram
-    HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST), c->stream));
-  }
+  if (!c->d_chemspread) return fail(c, "the chemistry counters are missing (c2r_create did not finish?)");
+  if (!c->isothermal && !c->d_defer[0]) return fail(c, "a non-isothermal pass before c2r_set_step declared the step non-isothermal");
   return 0;
 }
 

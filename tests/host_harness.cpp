@@ -221,12 +221,12 @@ int hh_constants(double *out, int n) {
 // the bilinear weights and the path length (bit for bit), and the corner positions -- equal to the general inverse
 // map wherever the corner's weight is not exactly zero, and inside shell s-1 where it is.  Returns the number of
 // mismatches (first one described in what[0..7]: shell, t, kind, corner).
-int hh_check_shell_geometry(int smax, int i0, int j0, int k0, int *what) {
+int hh_check_shell_geometry(int smin, int smax, int i0, int j0, int k0, int *what) {
   int bad = 0;
   auto note = [&](int s, int t, int kind, int c) {
     if (bad++ == 0 && what) { what[0] = s; what[1] = t; what[2] = kind; what[3] = c; }
   };
-  for (int s = 2; s <= smax; s++) {
+  for (int s = smin; s <= smax; s++) {
     const ShellGeom G = shell_geometry(s);
     if (G.alam * (double)s != (double)s - 0.5) note(s, -1, 0, 0); // the weight-zero argument rests on this
     const int cnt = (int)shell_count(s);

@@ -88,3 +88,16 @@ def test_no_null_stream_fills_outside_context_creation():
     # inside c2r_create the fills are followed by a device synchronisation
     create = src[start:end]
     assert create.rindex("hipDeviceSynchronize()") > create.rindex("hipMemset(")
+
+
+def test_no_allocation_inside_a_global_pass():
+    """Round 3 allocated the chemistry counters and the heating tiers' lists inside the first global pass: a hipMalloc is a
+    device-wide synchronisation in the middle of an iteration that has exactly one.  They now come from c2r_create and
+    c2r_set_step; the check a pass makes must not allocate."""
+    src = (ROOT / "c2-ray3dm1d_helium_amd" / "csrc" / "c2ray_hip.hip").read_text()
+    start = src.index("static int ensure_chemistry_buffers(")
+    body = src[start:src.index("\n}\n", start)]
+    assert "hipMalloc" not in body and "hipMemset" not in body
+    for fn in ("static int launch_chemistry(", 'extern "C" int c2r_global_pass_cells(', 'extern "C" int c2r_global_pass_finish('):
+        a = src.index(fn)
+        assert "hipMalloc" not in src[a:src.index("\n}\n", a)], fn

@@ -135,7 +135,16 @@ def test_per_shell_geometry_of_the_fast_sweep_equals_the_general_functions(harne
     short_characteristic + shell_position + shell_decode, every cell of shells 2..40 and a few large shells: decode,
     weights and path bit for bit; corner positions equal wherever the weight is not exactly zero."""
     what = (C.c_int * 8)()
-    assert harness.hh_check_shell_geometry(40, *src, what) == 0, list(what)
+    assert harness.hh_check_shell_geometry(2, 40, *src, what) == 0, list(what)
+
+
+@pytest.mark.parametrize("s", [127, 128, 255, 256, 639, 640])
+def test_per_shell_geometry_of_large_shells(harness, s):
+    """The same for single large shells, up to the last one the fast kernel serves (SHELL_FAST_MAX = 640): the magic
+    divisions of the thread -> cell map, the corner formulas and Markstein's path division have no small-shell bias to
+    hide behind (round-3 ADVICE: shells beyond 40 rested on the end-to-end GPU tests alone)."""
+    what = (C.c_int * 8)()
+    assert harness.hh_check_shell_geometry(s, s, 300, 17, 511, what) == 0, list(what)
 
 
 def test_per_shell_constants_hold_for_every_shell_of_the_largest_mesh(harness):
@@ -144,5 +153,3 @@ def test_per_shell_constants_hold_for_every_shell_of_the_largest_mesh(harness):
     shells it visits; here the arithmetic claim for all of them)."""
     s = np.arange(1, 4097, dtype=np.float64)
     assert np.array_equal(((s - 0.5) / s) * s, s - 0.5)
-    # a large shell end to end (24 s^2 + 2 cells): s = 300 alone, by giving smax = 300 to a harness that starts at 2 would
-    # take minutes; shells 296..300 are reached through the GPU tests at 512^3 and 600-cell meshes

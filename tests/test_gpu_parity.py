@@ -11,6 +11,7 @@ differences to the per-cent level (DESIGN.md "Conditioning").
 """
 import json
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -19,7 +20,8 @@ import pytest
 from conftest import rel_err, tap_case
 
 pytestmark = pytest.mark.gpu
-OUT = Path(__file__).resolve().parent.parent / "gpurun_out"
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "gpurun_out"
 
 
 def make_inputs(pkg, i):
@@ -1133,3 +1135,41 @@ def test_config4_workload_full_evolve3d_vs_oracle(pkg, orc, gold):
     assert niter > 3
     assert np.array_equal(mat.xh, s.xh_intermed) and np.array_equal(mat.xhe, s.xhe_intermed)
     assert np.array_equal(np.asarray(mat.temperature_grid)[:2 * nc], np.asarray(s.temperature)[:2 * nc])
+
+
+_SWEEP_SNIPPET = r'''
+import sys, numpy as np
+sys.path.insert(0, "{root}")
+import __graft_entry__ as ge, bench
+pkg = ge.load_package()
+n = 128
+mat, grid, src, cosmo = bench.config3_inputs(pkg, n, 3, seed=77)
+e = pkg.HipEngine((n, n, n), 0)
+e.set_tables(pkg.RadiationTables.load()); e.set_step(mat, grid, cosmo); e.set_sources(src); e.upload_state(mat)
+e.begin_step(); e.set_rates_to_zero()
+out = {{}}
+for ns in (1, 2, 3):
+    e.do_source(ns)
+    c = e.download_columns()
+    out["h%d" % ns], out["he%d" % ns] = c["coldensh_out"], c["coldenshe_out"]
+out.update(e.download_rates())
+np.savez("{out}", **out)
+'''
+
+
+def test_fast_sweep_equals_the_general_sweep(pkg, tmp_path):
+    """k_sweep_shell_fast (per-shell constants, 32-bit positions, Markstein divisions: shells 2..640) against the general
+    per-cell kernel for EVERY shell (C2R_SWEEP_GENERIC=1, read once per process: each side runs in a process of its own)
+    at 128^3 with three sources whose boxes run to the mesh limit (shells up to 64): every column of every source and the
+    rate grids bit for bit."""
+    import subprocess
+    res = {}
+    for tag, env in (("fast", {}), ("generic", {"C2R_SWEEP_GENERIC": "1"})):
+        out = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _SWEEP_SNIPPET.format(root=str(ROOT), out=str(out))], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    assert np.count_nonzero(res["fast"]["h1"]) > 0.9 * 128 ** 3        # the boxes do fill the mesh
+    for k in res["fast"].files:
+        assert np.array_equal(res["fast"][k], res["generic"][k]), k

@@ -42,8 +42,17 @@ def main():
             # wave-instructions; a wave64 instruction is 64 lane operations when every lane is active (an upper bound)
             fma, mul, add, trans = (x["per_launch"] for x in fl)
             res[k]["fp64_flop_per_launch_upper"] = 64.0 * (2.0 * fma + mul + add + trans)
+    # which sources the counters were taken from (bench.py quotes them only for the same sources)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import bench
+        res["source_sha16"] = bench.kernel_source_sha16()
+    except Exception as ex:  # noqa: BLE001
+        res["source_sha16"] = None
+        sys.stderr.write(f"pmc_summary: no source hash ({ex})\n")
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: v.get("hbm_bytes_per_launch_corrected") for k, v in res.items()}, indent=1))
+    print(json.dumps({k: v.get("hbm_bytes_per_launch_corrected") for k, v in res.items() if isinstance(v, dict)}, indent=1))
 
 
 if __name__ == "__main__":

@@ -85,7 +85,9 @@ def main():
         c["sweep_ms_by_iteration"] = [r[0] for r in rows]
     if not calls:
         raise SystemExit("no 'evolve3D loop' line in Timings.log")
-    out = {"binary": str(exe.relative_to(ROOT)), "mode": "stepwise" if a.stepwise else "c2r_iteration", "driver_wall_s": wall,
+    sys.path.insert(0, str(ROOT))
+    import bench
+    out = {"source_sha16": bench.kernel_source_sha16(), "binary": str(exe.relative_to(ROOT)), "mode": "stepwise" if a.stepwise else "c2r_iteration", "driver_wall_s": wall,
            "evolve3D_calls": calls, "iterations": calls[0]["iterations"], "ms_per_iteration": calls[0]["ms_per_iteration"]}
     # the Python host on the same iterations of the same first time step
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--neutral-start", "--warmup", "0", "--steps", str(calls[0]["iterations"]),
