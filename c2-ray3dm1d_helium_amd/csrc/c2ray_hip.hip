@@ -937,6 +937,12 @@ constexpr int CHEM_CTL_MAXWORK = CHEM_HIST, CHEM_CTL_MAXNIT = CHEM_HIST + 1, CHE
 #ifndef C2R_CHEM_WAVES
 #define C2R_CHEM_WAVES 2
 #endif
+#ifndef C2R_CHEM_XCD_CHUNK
+#define C2R_CHEM_XCD_CHUNK 64
+#endif
+#ifndef C2R_CHEM_CUBES
+#define C2R_CHEM_CUBES 1
+#endif
 // LDSTAB (heating only): the five cooling curves (32 KB) and the log's table (2 KB) in LDS.  A thermal sub-step is one
 // long chain of dependent operations, two of whose links are memory round trips -- the table of log10(T), then ten
 // cooling-curve entries -- and with two waves per SIMD nothing hides them: from LDS they cost a sixth.  Filling 34 KB
@@ -944,6 +950,9 @@ constexpr int CHEM_CTL_MAXWORK = CHEM_HIST, CHEM_CTL_MAXNIT = CHEM_HIST + 1, CHE
 // a handful of sub-steps, reads the tables from global memory and the repacked tiers after it use this variant;
 // blocks are two waves there, so that eight waves per compute unit still fit beside 4 x 34 KB.
 constexpr int CHEM_BLOCK_LDS = 128;
+#if defined(C2R_CHEM_NIT_HIST)
+__device__ unsigned long long c2r_chem_nit[64 * 136];
+#endif
 template <bool HEAT, bool LDSTAB = false>
 __global__ void __launch_bounds__(LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK, C2R_CHEM_WAVES)
 k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens, const double *__restrict__ xh,
@@ -951,8 +960,15 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
             double *__restrict__ xh_int, double *__restrict__ xhe_int, float *__restrict__ temperature,
             const double *__restrict__ rates, int *__restrict__ ctl, double *__restrict__ rc_last,
             const float *__restrict__ clumping_grid, size_t q_first, size_t q_end, const int *__restrict__ list,
-            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, double *__restrict__ packed) {
+            int budget, int *__restrict__ deferred, int *__restrict__ ndeferred, double *__restrict__ packed, int cubes) {
   // Cells are taken from the range [q_first, q_end) or, when `list` is given, from list[q_first .. q_end).
+  // cubes != 0 (a range of whole k-planes, mesh sizes multiples of 4): a wave takes a 4 x 4 x 4 cube of the range
+  // instead of 64 consecutive cells.  A wave lasts as long as its slowest lane, and the cells that need more
+  // do_chemistry iterations than their neighbours lie on surfaces (ionisation fronts, the edges of sub-boxes): a row of
+  // 64 cells crosses such a surface in one or two cells, a cube in sixteen -- an eighth as many waves are held up
+  // (profiles/r04_chem_nit.json: the first iteration of a time step in ionised gas has a mean of 2.2 iterations per cell
+  // and of 3.0 per row-shaped wave).  Cubes of one XCD are neighbours (runs of C2R_CHEM_XCD_CHUNK): the other three
+  // quarters of every 128-byte line a cube touches belong to the next cubes along i.
   // Heating runs: budget > 0 drops a cell whose thermal sub-cycling passes `budget` steps -- nothing of it is
   // stored -- and appends it to `deferred`, to be redone from scratch by a launch that holds only such cells
   // (c2r_global_pass_finish).  ctl: the spread counters (see CHEM_CTL_COPIES), among them the cells per power of
@@ -970,14 +986,38 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
   } else {
     sc.cd.logtab = nullptr; // known at compile time: coolin's choice of table folds away
   }
-  const size_t idx = q_first + (size_t)blockIdx.x * (LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK) + threadIdx.x;
+  size_t idx = q_first + (size_t)blockIdx.x * (LDSTAB ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK) + threadIdx.x;
+  size_t q_cube = 0;
+  if (!LDSTAB && cubes) {
+    constexpr int WPB = C2R_CHEM_BLOCK / 64; // waves per block
+    int vb = (int)blockIdx.x;
+    {
+      constexpr int C = C2R_CHEM_XCD_CHUNK;
+      const int full = (int)(gridDim.x / (8 * C)) * (8 * C);
+      if (vb < full) {
+        const int r = vb >> 3, xcd = vb & 7;
+        vb = (r / C) * (8 * C) + xcd * C + (r % C);
+      }
+    }
+    const int wv = vb * WPB + (int)(threadIdx.x >> 6), lane_ = (int)(threadIdx.x & 63);
+    // cubes == 1: 4 x 4 x 4 cells; cubes == 2: 8 x 4 x 2 (rows of 64 bytes)
+    const int si = cubes == 2 ? 3 : 2, sk = cubes == 2 ? 1 : 2; // log2 of the extent along i and k (along j: 4)
+    const int ci_n = g.n1 >> si, cj_n = g.n2 >> 2;
+    const int ci = wv % ci_n, cj = (wv / ci_n) % cj_n, ck = wv / (ci_n * cj_n);
+    const size_t plane = (size_t)g.n1 * g.n2;
+    const size_t k0 = q_first / plane;
+    const size_t i = (size_t)((ci << si) + (lane_ & ((1 << si) - 1))), j = (size_t)(4 * cj + ((lane_ >> si) & 3)),
+                 k = k0 + (size_t)((ck << sk) + (lane_ >> (si + 2)));
+    q_cube = i + (size_t)g.n1 * (j + (size_t)g.n2 * k);
+    idx = q_cube < q_end ? q_first : q_end; // in range (the launch covers whole cubes), or beyond it
+  }
   int notconv = 0;
   int bucket = -1;
   int work_done = 0, nit_done = 0;
   bool dropped = false;
   int q_dropped = 0;
   if (idx < q_end) {
-    const size_t q = list ? (size_t)list[idx] : idx;
+    const size_t q = list ? (size_t)list[idx] : ((!LDSTAB && cubes) ? q_cube : idx);
     int work = 0;
     // clumping_point for type_of_clumping = 5 (evolve_point.F90:483-484; REAL(4) grid)
     const double clumping = clumping_grid ? (double)clumping_grid[q] : sc.clumping;
@@ -1130,6 +1170,25 @@ k_chemistry(Grid g, StepScalars sc, double dt, const double *__restrict__ ndens,
   // conv_flag = conv_flag + 1 (evolve_point.F90:423): integer count, order-independent
   const unsigned long long m = __ballot(notconv);
   if (lane == 0 && m) atomicAdd(&my_ctl[CHEM_CTL_NOTCONV], (int)__popcll(m));
+#if defined(C2R_CHEM_NIT_HIST)
+  // diagnostic build (tools/chem_nit.py): do_chemistry iterations per cell [0..63], and per wave the largest of its
+  // lanes [64..127] and the sum over its lanes [128] -- a wave lasts as long as its slowest lane
+  {
+    unsigned long long *hc = c2r_chem_nit + (blockIdx.x & 63) * 136;
+    const int nb = nit_done < 63 ? nit_done : 63;
+    int nmx = nit_done;
+    long long nsum = nit_done;
+    for (int off = 32; off > 0; off >>= 1) {
+      nmx = max(nmx, __shfl_xor(nmx, off, 64));
+      nsum += __shfl_xor(nsum, off, 64);
+    }
+    if (idx < q_end) atomicAdd(hc + nb, 1ull);
+    if (lane == 0) {
+      atomicAdd(hc + 64 + (nmx < 63 ? nmx : 63), 1ull);
+      atomicAdd(hc + 128, (unsigned long long)nsum);
+    }
+  }
+#endif
 }
 
 // The spread counters of k_chemistry, folded (and zeroed for the next pass): the cells not converged are added to
@@ -1590,6 +1649,7 @@ struct c2r_ctx {
   double *h_loss = nullptr; // pinned, BATCH_MAX
   int *d_conv = nullptr;
   int *h_conv = nullptr;    // pinned
+  long long last_conv = -1;  // non-converged cells of the last global pass (-1: a step has just begun); shapes the next pass's waves
   int last_src = 0;
   double *last_cols = nullptr;      // column block of the last source swept (c2r_download_columns)
   size_t last_cz = 0;
@@ -2384,6 +2444,7 @@ static int begin_step_one(c2r_ctx *c) {
   HIPCHK(c, hipMemcpyAsync(c->d_xh_int, c->d_xh, sizeof(double) * 2 * nc, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_xhe_av, c->d_xhe, sizeof(double) * 3 * nc, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_xhe_int, c->d_xhe, sizeof(double) * 3 * nc, hipMemcpyDeviceToDevice, c->stream));
+  c->last_conv = -1;
   return 0;
 }
 
@@ -3362,21 +3423,32 @@ static int launch_chemistry(c2r_ctx *c, hipStream_t st, double dt, size_t first,
   const bool lds = !c->isothermal && list != nullptr && lds_tiers; // the repacked tiers of a heating pass
   const int bs = lds ? CHEM_BLOCK_LDS : C2R_CHEM_BLOCK;
   const int nblk = (int)((count + bs - 1) / bs);
+  // a range of whole k-planes on a mesh whose sizes are multiples of 4: waves take cubes (see the kernel)
+  const size_t plane = (size_t)g.n1 * g.n2;
+  // ... while the pass before left more than 1/64 of the cells unconverged (or a step has just begun): once nearly
+  // every cell is done after one iteration there is nothing to gain, and rows of 64 cells read their 17 grids in
+  // longer runs.  Same box, ms per pass over the 8 iterations of a time step in ionised gas, rows | 4x4x4 | 8x4x2 cells:
+  // 2.80 2.53 2.28 1.80 1.54 1.44 1.17 1.02 | 2.04 1.92 1.84 1.62 1.53 1.37 1.19 1.15 | 2.04 1.87 1.80 1.55 1.45 1.29 1.08 1.06.
+  // C2R_CHEM_CUBES=0 / 1 / 2 (environment): rows always / 4 x 4 x 4 always / 8 x 4 x 2 always; default: 8 x 4 x 2 by the rule.
+  static const int cubes_env = getenv("C2R_CHEM_CUBES") ? atoi(getenv("C2R_CHEM_CUBES")) : -1;
+  const bool busy = c->last_conv < 0 || c->last_conv * 64 > (long long)g.ncell;
+  const int cubes_want = cubes_env >= 0 ? cubes_env : (C2R_CHEM_CUBES && busy ? 2 : 0);
+  const int cubes = cubes_want && !list && g.n1 % 8 == 0 && g.n2 % 4 == 0 && first % plane == 0 && count % (4 * plane) == 0 ? cubes_want : 0;
   if (c->isothermal)
     hipLaunchKernelGGL(k_chemistry<false>, dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_chemspread,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, 0,
-                       (int *)nullptr, (int *)nullptr, c->d_stateT);
+                       (int *)nullptr, (int *)nullptr, c->d_stateT, cubes);
   else if (lds)
     hipLaunchKernelGGL((k_chemistry<true, true>), dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_chemspread,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_stateT);
+                       ndeferred, c->d_stateT, 0);
   else
     hipLaunchKernelGGL(k_chemistry<true>, dim3(nblk), dim3(bs), 0, st, g, sc, dt, c->d_ndens, c->d_xh,
                        c->d_xhe, c->d_xh_av, c->d_xhe_av, c->d_xh_int, c->d_xhe_int, c->d_temp, c->d_rates, c->d_chemspread,
                        c->d_rc_last, c->clumping_on_grid ? c->d_clump : nullptr, first, first + count, list, budget, deferred,
-                       ndeferred, c->d_stateT);
+                       ndeferred, c->d_stateT, cubes);
   HIPCHK(c, hipGetLastError());
   c->tm.chem_launches++;
   return 0;
@@ -3613,6 +3685,7 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     c->tm.chem_ms = ms;
   }
   if (conv_flag) *conv_flag = *c->h_conv;
+  c->last_conv = *c->h_conv;
   c->packed_valid = packed_now;
   c->transposed_valid = packed_now && !transpose_late;
   return 0;
@@ -3929,6 +4002,22 @@ extern "C" int c2r_synchronize(c2r_ctx *c) {
   return for_replicas(c, [&](c2r_ctx *r) { return synchronize_one(r); });
 }
 
+#ifdef C2R_CHEM_NIT_HIST
+// diagnostic build only: histogram of do_chemistry iterations (k_chemistry), read and optionally reset
+extern "C" int c2r_debug_chem_nit(unsigned long long out[136], int reset) {
+  static unsigned long long h[64 * 136];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(c2r_chem_nit), sizeof(h)) != hipSuccess) return 1;
+  for (int k = 0; k < 136; k++) {
+    out[k] = 0;
+    for (int s = 0; s < 64; s++) out[k] += h[s * 136 + k];
+  }
+  if (reset) {
+    memset(h, 0, sizeof(h));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c2r_chem_nit), h, sizeof(h)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 #ifdef C2R_RATES_COUNT
 // diagnostic build only: see count_lanes (c2ray_device.hpp)
 __device__ unsigned long long c2r::c2r_rates_cnt[64 * 24];
