@@ -76,6 +76,7 @@ SYMBOLS = {
     "c2r_global_pass_finish": (C.c_int, [C.c_void_p, _ip]),
     "c2r_end_step": (C.c_int, [C.c_void_p]),
     "c2r_download_rates": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
+    "c2r_download_rates_sel": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "c2r_get_loss": (C.c_int, [C.c_void_p, _dp, _ip]),
     "c2r_download_iter_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "c2r_download_columns": (C.c_int, [C.c_void_p, _dp, _dp]),

@@ -662,12 +662,28 @@ template <int N>
 C2R_HD void div_by_vol(const Recip &R, const double (&a)[N], double (&d)[N]) {
   double q[N];
   bool doubt = !R.ok_big;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(C2R_DIV_GUARD_F64)
+  // the guard on the high words: for q >= 0, q >= 2^-900 exactly when its high word, read as a signed integer, is >=
+  // 0x07B00000; a negative quotient has a negative high word and lands in the doubt branch, whose own test -- the
+  // one below, on the magnitudes -- then decides as it always did.  One v_min3_i32 and one compare for up to three
+  // quotients instead of a 64-bit compare each.
+  int m = 0x7fffffff;
+#pragma unroll
+  for (int n = 0; n < N; n++) {
+    q[n] = a[n] * R.y;
+    d[n] = __builtin_fma(__builtin_fma(-R.b, q[n], a[n]), R.y, q[n]);
+    const int hi = __double2hiint(q[n]);
+    m = hi < m ? hi : m;
+  }
+  doubt = doubt || m < 0x07B00000;
+#else
 #pragma unroll
   for (int n = 0; n < N; n++) {
     q[n] = a[n] * R.y;
     d[n] = __builtin_fma(__builtin_fma(-R.b, q[n], a[n]), R.y, q[n]);
     doubt = doubt || !(fabs(q[n]) >= 0x1p-900);
   }
+#endif
   C2R_COUNT_LANES(6, doubt);
   if (doubt) {
     bool redo = !R.ok_big;

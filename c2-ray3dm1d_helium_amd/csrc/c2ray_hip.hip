@@ -3713,6 +3713,13 @@ extern "C" int c2r_download_rates(c2r_ctx *c, double *phih, double *phihe, doubl
   return 0;
 }
 
+// the same for hosts that cannot pass a null pointer for an array (Fortran): bit 0 phih, bit 1 phihe, bit 2 phiheat
+extern "C" int c2r_download_rates_sel(c2r_ctx *c, int which, double *phih, double *phihe, double *phiheat, double *photon_loss47,
+                                      int *sum_nbox) {
+  return c2r_download_rates(c, (which & 1) ? phih : nullptr, (which & 2) ? phihe : nullptr, (which & 4) ? phiheat : nullptr,
+                            photon_loss47, sum_nbox);
+}
+
 extern "C" int c2r_get_loss(c2r_ctx *c, double *photon_loss47, int *sum_nbox) {
   if (!c) return 1;
   if (photon_loss47) std::memcpy(photon_loss47, c->photon_loss, sizeof c->photon_loss);

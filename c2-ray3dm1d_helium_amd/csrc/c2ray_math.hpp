@@ -175,7 +175,8 @@ C2R_MHD Log10Arg log10_split(double x) { // x positive, normal, finite
   const int i = (int)((uint32_t)k >> 31);
   a.ky = k + i;
   // (hi & 0xFFFFF) | (0x3ff - i) << 20: the sign bit is clear, so taking k + i out of the exponent field is a
-  // plain subtraction
+  // plain subtraction.  (Round 4 tried the other end -- mask the mantissa, select the exponent field of [1, 2) or
+  // [0.5, 1), and-or, subtract, shift: five operations on paper, seven in the compiler's hands -- and kept this.)
   a.hx = hi - ((uint32_t)a.ky << 20);
   return a;
 }

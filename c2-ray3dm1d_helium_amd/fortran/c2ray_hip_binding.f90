@@ -251,6 +251,15 @@ module c2ray_hip
        integer(c_int), intent(out) :: sum_nbox
      end function c2r_download_rates
 
+     integer(c_int) function c2r_download_rates_sel(ctx, which, phih, phihe, phiheat, photon_loss, sum_nbox) &
+          bind(C, name="c2r_download_rates_sel")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: which
+       real(c_double), intent(out) :: phih(*), phihe(*), phiheat(*), photon_loss(*)
+       integer(c_int), intent(out) :: sum_nbox
+     end function c2r_download_rates_sel
+
      integer(c_int) function c2r_get_loss(ctx, photon_loss, sum_nbox) bind(C, name="c2r_get_loss")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

@@ -84,6 +84,8 @@ module evolve
   logical :: fused_iterations = .true.
   logical :: fused_settings_read = .false.
   logical :: loop_timing = .false.
+  !> evolve_data's phiheat still holds the zeros it was allocated with (see download_rates)
+  logical :: phiheat_host_is_zero = .true.
   integer :: allreduce_slabs = 4
   !> what c2r_iteration reported about the iteration in flight, for global_pass to log
   type(c2r_iteration_report) :: report
@@ -528,14 +530,20 @@ contains
   !> phih_grid, phihe_grid, phiheat, photon_loss_all, sum_nbox to their host mirrors
   subroutine download_rates ()
 
-    integer(c_int) :: nbox
+    integer(c_int) :: nbox, which
 #ifdef C2RAY_REFERENCE_DO_SOURCE
     real(kind=dp) :: tail(NumFreqBnd)
+#endif
 
-    call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, tail, nbox), "c2r_download_rates")
+    ! phiheat stays zero in an isothermal run, on the device and in evolve_data's array (zeroed when allocated,
+    ! written by nobody else): no need to move 8 bytes per cell of zeros at every call
+    which = 7
+    if (isothermal .and. phiheat_host_is_zero) which = 3
+    if (.not.isothermal) phiheat_host_is_zero = .false.
+#ifdef C2RAY_REFERENCE_DO_SOURCE
+    call check (c2r_download_rates_sel (hip_ctx, which, phih_grid, phihe_grid, phiheat, tail, nbox), "c2r_download_rates")
 #else
-
-    call check (c2r_download_rates (hip_ctx, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
+    call check (c2r_download_rates_sel (hip_ctx, which, phih_grid, phihe_grid, phiheat, photon_loss_all, nbox), &
          "c2r_download_rates")
     sum_nbox=nbox
     sum_nbox_all=nbox
@@ -621,6 +629,7 @@ contains
        read(iterdump) xhe_intermed
        if (.not.isothermal) then
           read(iterdump) phiheat
+          phiheat_host_is_zero = .false.
           read(iterdump) temperature_grid
        endif
        close(iterdump)

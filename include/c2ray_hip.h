@@ -167,6 +167,11 @@ int c2r_end_step(c2r_ctx *ctx);
  * evolve.F90:457); evolve_source: sum_nbox.  Any pointer may be NULL. */
 int c2r_download_rates(c2r_ctx *ctx, double *phih, double *phihe, double *phiheat,
                        double *photon_loss47, int *sum_nbox);
+/* The same with the grids chosen by a mask (bit 0 phih, bit 1 phihe, bit 2 phiheat) instead of by null pointers, for
+ * hosts whose language cannot pass a null array: the Fortran drop-in leaves phiheat on the device in isothermal runs
+ * (the grid is zero there and on the host, evolve_data.F90:80 -- 134 MB of PCIe per evolve3D call at 256^3). */
+int c2r_download_rates_sel(c2r_ctx *ctx, int which, double *phih, double *phihe, double *phiheat,
+                           double *photon_loss47, int *sum_nbox);
 /* photon_loss(1:47) and sum_nbox of this rank's sources since the last c2r_set_rates_to_zero, from
  * the host-side bookkeeping (no device copy). */
 int c2r_get_loss(c2r_ctx *ctx, double *photon_loss47, int *sum_nbox);

@@ -186,11 +186,27 @@ def test_replicas_of_one_process_share_the_sources(pkg, gold, nrep):
     em, dt, src = _engine(pkg, gold, [0] * nrep)
     em.comm_init_local()
     assert em.num_devices() == nrep and em.comm_size() == nrep
+    assert em.rccl_ranks() == 0          # replicas that share a device are summed by the library itself (c2r_comm_kind == 2)
+    em.enable_timing(True)
     em.begin_step()
     em.set_rates_to_zero()
     em.pass_sources(1, 1)
+    # every replica's own pass is timed (c2r_get_timing_device): 3 sources over nrep replicas
+    swept = [em.timing(i).cells_swept for i in range(nrep)]
+    assert sum(1 for x in swept if x > 0) == min(3, nrep) and em.timing().cells_swept == swept[0]
+    with pytest.raises(pkg.C2RayHipError):
+        em.timing(nrep)
     em.allreduce_rates()
     got = em.download_rates()
+    # the grids chosen by a mask instead of by null pointers (c2r_download_rates_sel, for Fortran hosts)
+    import ctypes as C
+    n = em.ncell
+    a, b, h = np.full(n, -1.0), np.full(2 * n, -1.0), np.full(n, -1.0)
+    loss, nbox = np.empty(47), C.c_int(0)
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+    assert em.lib.c2r_download_rates_sel(em.h, 3, dp(a), dp(b), dp(h), dp(loss), C.byref(nbox)) == 0
+    assert np.array_equal(a, got["phih_grid"]) and np.array_equal(b, got["phihe_grid"]) and np.all(h == -1.0)
+    assert np.array_equal(loss, got["photon_loss"]) and nbox.value == got["sum_nbox"]
     # the same shares on single engines, summed in rank order on the host
     acc = None
     for r in range(nrep):
