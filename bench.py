@@ -440,7 +440,11 @@ def main():
             "roofline_valu_issue": None if n_instr is None else {
                 "bound": "valu-issue", "unit": "wave-instructions/s", "achieved": n_instr / (rates_per_launch_ms * 1e-3),
                 "peak": 1024 * 2.4e9 / 4.0, "frac": n_instr / (rates_per_launch_ms * 1e-3) / (1024 * 2.4e9 / 4.0),
-                "kernel": "k_rates", "instructions_per_launch": n_instr, "instructions": "stored counter (profiles/), live time"},
+                # the same priced with what was measured on this part instead of the nominal figures: 2.31 GHz under this
+                # kernel's load (tools/clock_probe.sh) and 4.3 cycles per FP64 wave-instruction (tools/micro/valu_rates.hip)
+                "frac_at_measured_clock_and_cost": n_instr / (rates_per_launch_ms * 1e-3) / (1024 * 2.31e9 / 4.3),
+                "kernel": "k_rates", "instructions_per_launch": n_instr, "instructions_per_cell_source": n_instr * 64.0 / max(1.0, cs_per_launch),
+                "instructions": "stored counter (profiles/, same sources as this run), live time; per cell.source: wave-instructions x 64 lanes / (cells x sources)"},
             # "report both HBM % and FP64 %".  FLOPs of one k_rates launch from the stored
             # SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 counters of this same command (wave-instructions x 64 lanes, an fma
             # counted twice: an upper bound, lanes masked off in divergent branches included) over the live launch time
@@ -460,7 +464,11 @@ def main():
                                       "achieved": COLUMN_BYTES_PER_CELL_SOURCE * swept / (sweep_ms * 1e-3) / 1e9,
                                       "note": "88 B per cell.source; all shell launches of a step incl. boundary-loss work"},
             "roofline_chemistry": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                   "achieved": CHEM_BYTES_PER_CELL * n ** 3 * a.steps / (chem_ms * 1e-3) / 1e9},
+                                   "achieved": CHEM_BYTES_PER_CELL * n ** 3 * a.steps / (chem_ms * 1e-3) / 1e9,
+                                   "state": ("CONVERGED STEADY STATE: every step of this run starts from the state the previous one left, so "
+                                             "after the warm-up nearly every cell is done after one do_chemistry iteration; where the pass is "
+                                             "expensive -- the first iterations of a time step -- is in chemistry_ms_in_a_time_step")
+                                   if not a.neutral_start else "from the neutral start"},
         }
         if comm is not None:
             del out["roofline_chemistry"]   # a span that overlaps the rates kernel is not a kernel time
@@ -489,7 +497,17 @@ def main():
             # binary from); quoted only when taken from the sources being timed
             dj, same = stored_profile(DROPIN_TIMING)
             if dj is not None and same:
-                out["dropin_ms_per_iteration"] = {k: dj[k] for k in ("ms_per_iteration", "iterations", "bench_ms_per_step_same_box", "evolve3D_calls", "note") if k in dj}
+                out["dropin_ms_per_iteration"] = {k: dj[k] for k in ("ms_per_iteration", "iterations", "bench_ms_per_step_same_box", "note") if k in dj}
+                calls = dj.get("evolve3D_calls", [])
+                out["dropin_ms_per_iteration"]["evolve3D_calls"] = [{k: c[k] for k in ("iterations", "ms_per_iteration", "setup_s", "results_s", "call_s", "kernel_ms_mean") if k in c} for c in calls]
+                # the chemistry pass where it is expensive (stored, same sources): by outer iteration of the neutral-start
+                # call (first ten) and of the time step after it
+                if calls and "chemistry_ms_by_iteration" in calls[0]:
+                    first = calls[0]["chemistry_ms_by_iteration"][:10]
+                    out["chemistry_ms_in_a_time_step"] = {
+                        "neutral_start_first_10_iterations": first, "neutral_start_first_10_mean": sum(first) / len(first),
+                        "second_time_step_by_iteration": calls[1]["chemistry_ms_by_iteration"] if len(calls) > 1 else None,
+                        "source": str(DROPIN_TIMING.relative_to(ROOT))}
             # the reference's own OpenMP build on THIS workload's inputs at THIS size, timed in the dev container
             # (tools/time_reference.py; the reference does not travel to the GPU box): stored and labelled so; it does not
             # depend on this library's sources
