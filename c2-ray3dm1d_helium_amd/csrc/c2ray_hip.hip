@@ -82,10 +82,6 @@ __device__ __forceinline__ int wrap0(int x, int n) { // 0-based periodic index o
   const unsigned lo = a < b ? a : b;
   return (int)(u < lo ? u : lo);
 }
-__device__ __forceinline__ size_t cell_index(const Grid &g, int i0, int j0, int k0, int di, int dj, int dk) {
-  int i = wrap0(i0 - 1 + di, g.n1), j = wrap0(j0 - 1 + dj, g.n2), k = wrap0(k0 - 1 + dk, g.n3);
-  return (size_t)i + (size_t)g.n1 * ((size_t)j + (size_t)g.n2 * (size_t)k);
-}
 
 __device__ __forceinline__ double block_sum(double x, double *sh) {
   // fixed-shape tree: wave shuffle, then the 4 wave sums in order -> deterministic
@@ -331,70 +327,6 @@ k_loss_stored(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ li
   if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + bx] = bs;
 }
 
-// ---------------------------------------------------------------------------------------------
-// A quick LOWER BOUND of that loss, to decide "this source goes on" without waiting for the full sum: of every
-// `sample`-th block of the round's shells, 8 cells (every 32nd), each cell's bands spread over 32 lanes -- a thread
-// evaluates one or two bands, so the launch lasts microseconds where a thread of k_loss walks all bands of
-// its cell.  Every term is a non-negative photon count, so any subset, in any order, bounds the loss from below;
-// a bound that clears the threshold of evolve_source.F90:136 with a factor 2 to spare is decisive, anything else
-// is replaced by the full sum of k_loss.  No bit of any result depends on this kernel.
-__global__ void __launch_bounds__(BLOCK)
-k_loss_probe(Grid g, const SrcDev *__restrict__ src, const int *__restrict__ list, int multi, int s_lo, int s_hi, Box box,
-             StepScalars sc, const BandData *__restrict__ bd, SedSet ss,
-             const int *__restrict__ block_base, double *__restrict__ loss_partial, int pitch, int sample) {
-  __shared__ double sh[BLOCK / 64];
-  const SrcDev &S = src[list[blockIdx.y]];
-  // every sample-th block counted from the END of the round: the surface of the box is mostly its outermost shell,
-  // and the last block of the round is always looked at (counted from the front, the 43 blocks of round 1 put
-  // blocks 0, 16 and 32 in shells 0, 7 and 9: no surface cell, no decision, the full sum every time)
-  const int B = block_base[s_hi + 1] - 1 - (int)blockIdx.x * sample;
-  int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (block_base[mid] <= B) lo = mid; else hi = mid - 1;
-  }
-  const int shell = lo;
-  const long long cnt = shell_count(shell);
-  const int slot = threadIdx.x & 31;
-  const long long t = (long long)(B - block_base[shell]) * BLOCK + (threadIdx.x >> 5) * 32;
-  double loss = 0.0;
-  if (t < cnt) {
-    int di, dj, dk;
-    shell_decode(shell, (int)t, di, dj, dk);
-    const bool inside = di >= box.lo[0] && di <= box.hi[0] && dj >= box.lo[1] && dj <= box.hi[1] && dk >= box.lo[2] &&
-                        dk <= box.hi[2];
-    const bool boundary = di == box.lo[0] || dj == box.lo[1] || dk == box.lo[2] || di == box.hi[0] || dj == box.hi[1] ||
-                          dk == box.hi[2];
-    if (inside && boundary) {
-      const size_t cz = S.cz;
-      const size_t p = (size_t)shell_offset(shell) + (size_t)t;
-      const global_double *cs = (const global_double *)S.cols;
-      const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
-      const double cout_HI = cs[col_out(p, 0, cz)], cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
-      if (cin_HI < max_coldensh) {
-        double vol_ph;
-        if (shell == 0) {
-          vol_ph = sc.dr1 * sc.dr2 * sc.dr3;
-        } else {
-          const double path = sc_path(di, dj, dk) * sc.dr1;
-          const double xs = sc.dr1 * (double)di, ys = sc.dr2 * (double)dj, zs = sc.dr3 * (double)dk;
-          vol_ph = 4.0 * pi * (xs * xs + ys * ys + zs * zs) * path;
-        }
-        const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-        double po = 0.0;
-        for (int sd = 0; sd < (multi ? NSED : 1); sd++) {
-          if (!(nf[sd] > 0.0)) continue;
-          for (int b = ss.lo[sd] + slot; b < ss.hi[sd]; b += 32)
-            po += photo_out_band(*bd, sd, ss.photo_thick[sd], ss.photo_thin[sd], b, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII,
-                                 cout_HeII, nf[sd]);
-        }
-        loss = po * sc.vol / vol_ph;
-      }
-    }
-  }
-  const double bs = block_sum(loss, sh);
-  if (threadIdx.x == 0) loss_partial[(size_t)blockIdx.y * pitch + blockIdx.x] = bs;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Column sweep of one shell for every active source of the batch (blockIdx.y counts `active`).
@@ -577,6 +509,12 @@ k_loss_finish(const double *__restrict__ loss_partial, int pitch, int count, dou
   if (threadIdx.x == 0) loss_acc[blockIdx.x] = tot;
 }
 
+// A quick LOWER BOUND of that loss, to decide "this source goes on" without waiting for the full sum: of every
+// `sample`-th block of the round's shells, 8 cells (every 32nd), each cell's bands spread over 32 lanes -- a thread
+// evaluates one or two bands, so the launch lasts microseconds where a thread of k_loss walks all bands of
+// its cell.  Every term is a non-negative photon count, so any subset, in any order, bounds the loss from below;
+// a bound that clears the threshold of evolve_source.F90:136 with a factor 2 to spare is decisive, anything else
+// is replaced by the full sum of k_loss.  No bit of any result depends on this kernel.
 // The probes of several rounds of a batch in ONE launch (blockIdx.z counts the rounds): the rounds that were swept on
 // trust are probed together, and two launches (this one and k_loss_finish_rounds) instead of two per round keep the
 // probe's footprint on the device at a few microseconds.
@@ -598,7 +536,7 @@ k_loss_probe_rounds(Grid g, const SrcDev *__restrict__ src, const int *__restric
   if ((int)blockIdx.x >= R.nblk || (int)blockIdx.y >= R.nact) return; // uniform per block
   const SrcDev &S = src[lists[R.list_off + blockIdx.y]];
   const int s_lo = R.s_lo, s_hi = R.s_hi;
-  // every sample-th block counted from the END of the round (see k_loss_probe)
+  // every sample-th block counted from the END of the round (the surface of a box is mostly its outermost shell)
   const int B = block_base[s_hi + 1] - 1 - (int)blockIdx.x * sample;
   int lo = s_lo, hi = s_hi; // largest shell with block_base[shell] <= B
   while (lo < hi) {
@@ -2543,7 +2481,6 @@ static int pool_event(c2r_ctx *c, hipEvent_t *out) {
   return 0;
 }
 
-constexpr int LOSS_SAMPLE = 16; // a sampled boundary loss evaluates every 16th block of the round's shells
 
 // Photon loss of the round's box for the sources h_list[set][list_off .. +n) (positions in the batch), full
 // (sample = 1) or sampled, into c->h_loss[0..n).  Synchronises the sweep stream.
@@ -2593,7 +2530,7 @@ struct RoundRec {
   Box box{};
 };
 
-// Queue the probes of the rounds recs[from .. to) (lower bounds of their boundary losses, k_loss_probe) on the probe
+// Queue the probes of the rounds recs[from .. to) (lower bounds of their boundary losses, k_loss_probe_rounds) on the probe
 // stream, behind everything queued on the sweep stream so far, and the copy of all their results to h_probe; ev_probe
 // marks the end.  Does not wait.  One event on the sweep stream for all of them: the rounds of a batch whose
 // sources are all expected to go on (prev_nbox) are probed together, late, and the sweep stream sees no probe
@@ -2826,7 +2763,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
     long long batch_cells = 0;
     int *hl = c->h_list[set];
     // The sub-box loop (evolve_source.F90:136-144).  After the shells of round r the loss through the box surface
-    // decides who sweeps round r+1; a quick lower bound of it (k_loss_probe) nearly always does.  When every active
+    // decides who sweeps round r+1; a quick lower bound of it (k_loss_probe_rounds) nearly always does.  When every active
     // source went beyond round r in the previous pass (prev_nbox), round r+1 is launched at once for all of them, on
     // trust, and the probe of round r is not even queued yet: the probes of all such rounds go out together, on
     // their own stream, when a decision is really needed -- before a round that some source did not reach last time,
