@@ -121,7 +121,41 @@ struct BandData {
   // per SED (black body, power law, quasar) and band: the optical depth from which every table entry a lookup
   // of that band can touch is exactly 0 (band_tau_zero); +inf when there is no such depth
   double tau_zero[3][NFREQ];
+  // The same cross sections and factors once more, band by band (band_rows_fill): what one band of the rates kernels
+  // reads lies in 128 consecutive bytes -- two lines of the scalar cache and a few wide scalar loads instead of fifteen
+  // loads from fifteen lines.  f: f1ion_{HI,HeI,HeII}, f2ion_.., f1heat_.., f2heat_.. of band b (0 for band 1, whose
+  // arrays start at band 2).
+  struct Row {
+    double sigma[3], pad;
+    double f[12];
+  } rows[NFREQ];
 };
+// fills BandData::rows from the arrays above (host side, before the struct goes to the device)
+inline void band_rows_fill(BandData &bd) {
+  for (int b = 0; b < NFREQ; b++) {
+    BandData::Row &r = bd.rows[b];
+    r.sigma[0] = bd.sigma_HI[b]; r.sigma[1] = bd.sigma_HeI[b]; r.sigma[2] = bd.sigma_HeII[b];
+    r.pad = 0.0;
+    const double *src[12] = {bd.f1ion_HI, bd.f1ion_HeI, bd.f1ion_HeII, bd.f2ion_HI, bd.f2ion_HeI, bd.f2ion_HeII,
+                             bd.f1heat_HI, bd.f1heat_HeI, bd.f1heat_HeII, bd.f2heat_HI, bd.f2heat_HeI, bd.f2heat_HeII};
+    for (int k = 0; k < 12; k++) r.f[k] = b >= 1 ? src[k][b - 1] : 0.0;
+  }
+}
+// A kernel says which of the two copies its band loops read by the TYPE it hands down: BandData (the per-species
+// arrays) or BandDataByRow (the same object, read band by band).  Measured on one box: the rows are worth 4 % to the
+// heating kernel with three SEDs (355 -> 341 ms per 128-source pass: fifteen scalar loads per band and SED become
+// four wide ones) and cost the isothermal and the one-SED heating kernels 0.5 % (wide loads want aligned blocks of
+// scalar registers, which those kernels are short of: 24 instead of 12 spilled), so only the former asks for them.
+struct BandDataByRow : BandData {};
+C2R_HD double band_sigma(const BandData &bd, int b, int k) { return k == 0 ? bd.sigma_HI[b] : (k == 1 ? bd.sigma_HeI[b] : bd.sigma_HeII[b]); }
+C2R_HD double band_sigma(const BandDataByRow &bd, int b, int k) { return bd.rows[b].sigma[k]; }
+// factor n = 0..11 of band b >= 1: f1ion_{HI,HeI,HeII}, f2ion_.., f1heat_.., f2heat_..
+C2R_HD double band_f(const BandData &bd, int b, int n) {
+  const double *const v[12] = {bd.f1ion_HI, bd.f1ion_HeI, bd.f1ion_HeII, bd.f2ion_HI, bd.f2ion_HeI, bd.f2ion_HeII,
+                               bd.f1heat_HI, bd.f1heat_HeI, bd.f1heat_HeII, bd.f2heat_HI, bd.f2heat_HeI, bd.f2heat_HeII};
+  return v[n][b - 1]; // the arrays are dimension(2:47)
+}
+C2R_HD double band_f(const BandDataByRow &bd, int b, int n) { return bd.rows[b].f[n]; }
 
 C2R_HD double dmax(double a, double b) { return a > b ? a : b; }
 C2R_HD double dmin(double a, double b) { return a < b ? a : b; }
@@ -712,8 +746,8 @@ struct BandShared {
   TauPos pin, pout;
   double sc_HI, sc_HeI, sc_HeII;
 };
-template <bool HEAT, int CLS, class RIC>
-C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
+template <bool HEAT, int CLS, class RIC, class BD = BandData>
+C2R_HD void band_sed(const BD &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
                      const double *heat_thin, int b, const CellSrc &c, double NFlux, const BandShared &B, const RIC &ric,
                      SedSums &o) {
   const double sHI = B.sHI, sHeI = B.sHeI, sHeII = B.sHeII, dtau = B.dtau;
@@ -794,11 +828,10 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
       div_by_vol<2>(c.rvol, a, h);
       const double h_HI = h[0], h_HeI = h[1];
       df_heat = h_HI + h_HeI;
-      const int q = b - 1; // f arrays are dimension(2:47)
-      const double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI;
-      const double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI;
-      const double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI;
-      const double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI;
+const double fra_sum1 = band_f(bd, b, 0) * h_HI + band_f(bd, b, 1) * h_HeI;
+      const double fra_sum2 = band_f(bd, b, 3) * h_HI + band_f(bd, b, 4) * h_HeI;
+      const double fra_sum3 = band_f(bd, b, 6) * h_HI + band_f(bd, b, 7) * h_HeI;
+      const double fra_sum4 = band_f(bd, b, 9) * h_HI + band_f(bd, b, 10) * h_HeI;
       o.df_ion_HeI = ric_y1(ric, 1) * fra_sum1 - ric_y2(ric, 1) * fra_sum2;
       o.df_ion_HI = ric_y1(ric, 0) * fra_sum1 - ric_y2(ric, 0) * fra_sum2;
       df_heat = df_heat - ric_y1(ric, 2) * fra_sum3 + ric_y2(ric, 2) * fra_sum4;
@@ -825,11 +858,10 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
       div_by_vol<3>(c.rvol, a, h);
       const double h_HI = h[0], h_HeI = h[1], h_HeII = h[2];
       df_heat = h_HI + h_HeI + h_HeII;
-      const int q = b - 1;
-      const double fra_sum1 = bd.f1ion_HI[q] * h_HI + bd.f1ion_HeI[q] * h_HeI + bd.f1ion_HeII[q] * h_HeII;
-      const double fra_sum2 = bd.f2ion_HI[q] * h_HI + bd.f2ion_HeI[q] * h_HeI + bd.f2ion_HeII[q] * h_HeII;
-      const double fra_sum3 = bd.f1heat_HI[q] * h_HI + bd.f1heat_HeI[q] * h_HeI + bd.f1heat_HeII[q] * h_HeII;
-      const double fra_sum4 = bd.f2heat_HI[q] * h_HI + bd.f2heat_HeI[q] * h_HeI + bd.f2heat_HeII[q] * h_HeII;
+const double fra_sum1 = band_f(bd, b, 0) * h_HI + band_f(bd, b, 1) * h_HeI + band_f(bd, b, 2) * h_HeII;
+      const double fra_sum2 = band_f(bd, b, 3) * h_HI + band_f(bd, b, 4) * h_HeI + band_f(bd, b, 5) * h_HeII;
+      const double fra_sum3 = band_f(bd, b, 6) * h_HI + band_f(bd, b, 7) * h_HeI + band_f(bd, b, 8) * h_HeII;
+      const double fra_sum4 = band_f(bd, b, 9) * h_HI + band_f(bd, b, 10) * h_HeI + band_f(bd, b, 11) * h_HeII;
       o.df_ion_HeI = ric_y1(ric, 1) * fra_sum1 - ric_y2(ric, 1) * fra_sum2;
       o.df_ion_HI = ric_y1(ric, 0) * fra_sum1 - ric_y2(ric, 0) * fra_sum2;
       df_heat = df_heat - ric_y1(ric, 2) * fra_sum3 + ric_y2(ric, 2) * fra_sum4;
@@ -841,19 +873,19 @@ C2R_HD void band_sed(const BandData &bd, const double *photo_thick, const double
 }
 
 // The optical depths of band b at the two faces of the cell, and the band's cross sections (into B)
-template <int CLS>
-C2R_HD void band_depths(const BandData &bd, int b, const CellSrc &c, BandShared &B, double &tau_in, double &tau_out) {
-  const double sHI = bd.sigma_HI[b];
+template <int CLS, class BD = BandData>
+C2R_HD void band_depths(const BD &bd, int b, const CellSrc &c, BandShared &B, double &tau_in, double &tau_out) {
+  const double sHI = band_sigma(bd, b, 0);
   double sHeI = 0.0, sHeII = 0.0;
   tau_in = c.cin_HI * sHI;
   tau_out = c.cout_HI * sHI;
   if (CLS >= 1) {
-    sHeI = bd.sigma_HeI[b];
+    sHeI = band_sigma(bd, b, 1);
     tau_in = tau_in + c.cin_HeI * sHeI;
     tau_out = tau_out + c.cout_HeI * sHeI;
   }
   if (CLS >= 2) {
-    sHeII = bd.sigma_HeII[b];
+    sHeII = band_sigma(bd, b, 2);
     tau_in = tau_in + c.cin_HeII * sHeII;
     tau_out = tau_out + c.cout_HeII * sHeII;
   }
@@ -896,8 +928,8 @@ C2R_HD void band_positions(const LT *logtab, const CellSrc &c, double tau_in, do
 // `look_for_zero`: test whether the band is beyond the last non-zero table entry (band_tau_zero); returns
 // whether it was.  Within a class the optical depth falls from band to band, so once no lane of a wave has
 // found a band dead the caller stops asking (a missed skip costs time, never a bit).
-template <bool HEAT, int CLS, class LT, class RIC>
-C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
+template <bool HEAT, int CLS, class LT, class RIC, class BD = BandData>
+C2R_HD bool band_rates(const BD &bd, const double *photo_thick, const double *photo_thin, const double *heat_thick,
                        const double *heat_thin, const LT *logtab, const double *tau_zero, bool look_for_zero, int b,
                        const CellSrc &c, const RIC &ric, SedSums &o) {
   BandShared B;
@@ -918,8 +950,8 @@ C2R_HD bool band_rates(const BandData &bd, const double *photo_thick, const doub
 // their band range): optical depths, logs, table positions and species split once, then each SED's look-ups and sums
 // exactly as band_rates makes them -- every sum sees the same operands in the same order.  dead[k]: band_rates' return
 // value for SED k.
-template <bool HEAT, int CLS, class LT, class RIC>
-C2R_HD void band_rates_pair(const BandData &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
+template <bool HEAT, int CLS, class LT, class RIC, class BD = BandData>
+C2R_HD void band_rates_pair(const BD &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
                             const double *const (&heat_thick)[2], const double *const (&heat_thin)[2], const LT *logtab,
                             const double *const (&tau_zero)[2], const bool (&look_for_zero)[2], int b, const CellSrc &c,
                             const double (&NFlux)[2], const RIC &ric, SedSums (&o)[2], bool (&dead)[2]) {
@@ -949,8 +981,8 @@ struct SedAcc {
 // heat_lookuptable (:470-779), scale_int2/3 (:787-823) fused into one pass over the active bands
 // [blo, bhi) (0-based), in three stretches by band class; every sum runs in band order as in the reference.
 // HEAT selects the non-isothermal path.  `logtab`: see tau_table_position.
-template <bool HEAT, class LT, class RIC>
-C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
+template <bool HEAT, class LT, class RIC, class BD = BandData>
+C2R_HD void sed_rates(const BD &bd, const double *photo_thick, const double *photo_thin,
                       const double *heat_thick, const double *heat_thin, int blo, int bhi, double cin_HI,
                       double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
                       double NFlux, const RIC &ric, SedAcc &out, const LT *logtab, const double *tau_zero,
@@ -1004,8 +1036,8 @@ C2R_HD void sed_rates(const BandData &bd, const double *photo_thick, const doubl
 
 // sed_rates for two SEDs with the same band range at once (band_rates_pair): out[k] is bit for bit what
 // sed_rates(tables of k, NFlux[k]) returns
-template <bool HEAT, class LT, class RIC>
-C2R_HD void sed_rates_pair(const BandData &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
+template <bool HEAT, class LT, class RIC, class BD = BandData>
+C2R_HD void sed_rates_pair(const BD &bd, const double *const (&photo_thick)[2], const double *const (&photo_thin)[2],
                            const double *const (&heat_thick)[2], const double *const (&heat_thin)[2], int blo, int bhi,
                            double cin_HI, double cout_HI, double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII,
                            double vol, const double (&NFlux)[2], const RIC &ric, SedAcc (&out)[2], const LT *logtab,
@@ -1054,8 +1086,8 @@ C2R_HD void sed_rates_pair(const BandData &bd, const double *const (&photo_thick
 }
 
 // photoion_rates for a source with the black-body SED only
-template <bool HEAT, class LT = double, class RIC = Ricotti>
-C2R_HD void photoion_rates(const BandData &bd, const double *photo_thick, const double *photo_thin,
+template <bool HEAT, class LT = double, class RIC = Ricotti, class BD = BandData>
+C2R_HD void photoion_rates(const BD &bd, const double *photo_thick, const double *photo_thin,
                            const double *heat_thick, const double *heat_thin, double cin_HI, double cout_HI,
                            double cin_HeI, double cout_HeI, double cin_HeII, double cout_HeII, double vol,
                            double NFlux, const RIC &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
@@ -1087,8 +1119,8 @@ struct SedSet {
   int lo[NSED], hi[NSED]; // 0-based first band, one past the last band; lo == hi: SED absent
 };
 
-template <bool HEAT, class LT = double, class RIC = Ricotti>
-C2R_HD void photoion_rates_multi(const BandData &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
+template <bool HEAT, class LT = double, class RIC = Ricotti, class BD = BandData>
+C2R_HD void photoion_rates_multi(const BD &bd, const SedSet &ss, double cin_HI, double cout_HI, double cin_HeI,
                                  double cout_HeI, double cin_HeII, double cout_HeII, double vol, const double *NFlux,
                                  const RIC &ric, PhotoOut &o, const LT *logtab = C2R_LOGTAB_DEFAULT,
                                  const gm::LogPins *pins = nullptr) {

@@ -633,6 +633,9 @@ k_col_to_grid(Grid g, SrcDev S, const double *__restrict__ cs, double *__restric
 #ifndef C2R_RATES_XCD_CHUNK
 #define C2R_RATES_XCD_CHUNK 128
 #endif
+#ifndef C2R_RATES_BAND_ROWS
+#define C2R_RATES_BAND_ROWS 1
+#endif
 #ifndef C2R_RATES_PARK_RICOTTI
 #define C2R_RATES_PARK_RICOTTI 0
 #endif
@@ -799,7 +802,11 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
         PhotoOut o;
         if (MULTI) {
           const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
-          photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, &s_logtab[0], pins);
+          if constexpr (HEAT && (C2R_RATES_BAND_ROWS)) // this kernel reads cross sections and factors band by band (BandDataByRow)
+            photoion_rates_multi<HEAT>(*static_cast<const BandDataByRow *>(bd), ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII,
+                                       vol_ph, nf, ric, o, &s_logtab[0], pins);
+          else
+            photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, &s_logtab[0], pins);
         } else {
           photoion_rates<HEAT>(*bd, ss.photo_thick[0], ss.photo_thin[0], ss.heat_thick[0], ss.heat_thin[0], cin_HI, cout_HI,
                                cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, S.nflux, ric, o, &s_logtab[0], pins);
@@ -1480,7 +1487,8 @@ struct c2r_ctx {
   // the column-wise copies above (and d_sed_tab[][2..3]) stay for c2r_download_tables and band_tau_zero
   double *d_heat_woven[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   BandData *d_bands = nullptr;
-  BandData h_bands{};              // host copy (tau_zero is refreshed whenever a table set changes)
+  BandDataByRow h_bands{};         // host copy (tau_zero is refreshed whenever a table set changes); what d_bands holds: a BandData
+                                   // whose band-by-band copy is filled in, which the three-SED heating kernel reads as BandDataByRow
   bool have_tables = false, have_heat_tables = false, have_bands = false, have_fvec = false;
   int bb_upper = 0;
   double *d_cool = nullptr;
@@ -1991,7 +1999,10 @@ static int refresh_tau_zero(c2r_ctx *c, int sed) {
       }
     }
   }
-  if (c->have_bands) HIPCHK(c, hipMemcpy(c->d_bands, &c->h_bands, sizeof(BandData), hipMemcpyHostToDevice));
+  if (c->have_bands) {
+    band_rows_fill(c->h_bands);
+    HIPCHK(c, hipMemcpy(c->d_bands, &c->h_bands, sizeof(BandData), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -2054,7 +2065,7 @@ static int set_tables_one(c2r_ctx *c, const double *photo_thick, const double *p
   if (!c->have_bands)
     for (int sd = 0; sd < 3; sd++)
       for (int b = 0; b < NFREQ; b++) bd.tau_zero[sd][b] = (double)INFINITY;
-  c->h_bands = bd;
+  static_cast<BandData &>(c->h_bands) = bd;
   c->bb_upper = bb_upper;
   c->have_bands = true;
   return refresh_tau_zero(c, 0); // uploads the band data too

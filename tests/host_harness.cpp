@@ -14,7 +14,7 @@ using namespace c2r;
 
 namespace {
 struct Tables {
-  BandData bd;
+  BandDataByRow bd; // (a BandData with its band-by-band copy filled: band_rows_fill)
   std::vector<double> pthick, pthin, hthick, hthin, cool;
   std::vector<double> hthick_il, hthin_il; // as the product's kernels read them (heat_interleave)
   double mintemp, dtemp;
@@ -64,6 +64,7 @@ void hh_set_tables(const double *pthick, const double *pthin, const double *hthi
                      T.bd.f1heat_HI, T.bd.f1heat_HeI, T.bd.f1heat_HeII, T.bd.f2heat_HI, T.bd.f2heat_HeI, T.bd.f2heat_HeII};
   for (int i = 0; i < 12; i++) std::memcpy(dst[i], f[i], sizeof(double) * (NFREQ - 1));
   T.bd.bb_upper = bb_upper;
+  band_rows_fill(T.bd);
   set_tau_zero(0, T.pthick, T.pthin, T.hthick, T.hthin);
   T.hthick_il.resize(T.hthick.size());
   T.hthin_il.resize(T.hthin.size());
@@ -135,6 +136,17 @@ void hh_photoion_multi(const double *cin6, double vol, const double *nflux3, dou
   if (heat) ric = ricotti_parameters(i_state);
   if (heat) photoion_rates_multi<true>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, ric, o);
   else photoion_rates_multi<false>(T.bd, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, ric, o);
+  out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
+}
+// the same through BandDataByRow (what the three-SED heating kernel hands down: cross sections and factors read band by band)
+void hh_photoion_multi_rows(const double *cin6, double vol, const double *nflux3, double i_state, int heat, double *out5) {
+  PhotoOut o;
+  const SedSet ss = make_sedset();
+  const BandDataByRow &bdr = static_cast<const BandDataByRow &>(T.bd);
+  Ricotti ric = {};
+  if (heat) ric = ricotti_parameters(i_state);
+  if (heat) photoion_rates_multi<true>(bdr, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, ric, o);
+  else photoion_rates_multi<false>(bdr, ss, cin6[0], cin6[1], cin6[2], cin6[3], cin6[4], cin6[5], vol, nflux3, ric, o);
   out5[0] = o.photo_HI; out5[1] = o.photo_HeI; out5[2] = o.photo_HeII; out5[3] = o.heat; out5[4] = o.photo_out;
 }
 double hh_photo_out_multi(const double *cin6, const double *nflux3) {

@@ -125,6 +125,10 @@ def test_multi_sed_photoion_equals_oracle(hh, orc, pkg, gold):
                                           (C.c_double * 3)(*nf), C.c_double(row[7]), C.c_int(1 - heat), C.byref(ref))
             r = ref.as_array()
             assert np.array_equal(out, r[[0, 1, 2, 18, 20]]), (n, heat)
+            # ... and with cross sections and factors read band by band (BandDataByRow, the three-SED heating kernel)
+            out_rows = np.empty(5)
+            hh.hh_photoion_multi_rows(_p(cin), C.c_double(row[6]), _p(nf), C.c_double(row[7]), C.c_int(heat), _p(out_rows))
+            assert np.array_equal(out_rows, out), (n, heat, "rows")
         hh.hh_photo_out_multi.restype = C.c_double
         assert hh.hh_photo_out_multi(_p(cin), _p(nf)) == r[20]
 
