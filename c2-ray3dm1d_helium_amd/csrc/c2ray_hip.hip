@@ -784,6 +784,19 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
     const double cout_HI = cs[col_out(p, 0, cz)];
     const double cin_HI = cs[col_in(p, 0, cz)], cin_HeI = cs[col_in(p, 1, cz)], cin_HeII = cs[col_in(p, 2, cz)];
     const double cout_HeI = cs[col_out(p, 1, cz)], cout_HeII = cs[col_out(p, 2, cz)];
+#if defined(C2R_RATES_DUMMY_TRAFFIC)
+    // EXPERIMENT (never in the product): the column sweep's compulsory traffic -- 96 bytes per cell.source, half read, half
+    // written -- moved by this kernel on top of its own, to see what a fused sweep + rates kernel could hope to hide
+    // behind the band loops.  Reads come from another part of the source's block, the writes go back there unchanged.
+    {
+      const size_t p2 = (p + cz / 2) % cz;
+      double d0 = cs[col_in(p2, 0, cz)], d1 = cs[col_in(p2, 1, cz)], d2 = cs[col_in(p2, 2, cz)];
+      double d3 = cs[col_out(p2, 0, cz)], d4 = cs[col_out(p2, 1, cz)], d5 = cs[col_out(p2, 2, cz)];
+      asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5)); // opaque: the stores are not "the value just loaded"
+      cs[col_in(p2, 0, cz)] = d0; cs[col_in(p2, 1, cz)] = d1; cs[col_in(p2, 2, cz)] = d2;
+      cs[col_out(p2, 0, cz)] = d3; cs[col_out(p2, 1, cz)] = d4; cs[col_out(p2, 2, cz)] = d5;
+    }
+#endif
     double vol_ph;
     if (di == 0 && dj == 0 && dk == 0) {
       vol_ph = sc.cellvol;
