@@ -210,6 +210,30 @@ def cpu_baseline_reference(mesh=64):
                       f"isothermal, {niter} outer iterations of evolve3D in {total:.1f} s (nominal mesh^3 x sources per iteration, as the metric)"}
 
 
+def cpu_baseline_reference_at_size(mesh=256, iterations=2):
+    """The reference ITSELF on the benchmark's own inputs at the benchmark's own size, on THIS box's host cores: the timed
+    build (oracle/ref_build.sh 256 omp timer -> oracle/_ref/N256_omp/C2Ray_3D_timed, made in the dev container, travels
+    in oracle/_ref/) run for its first `iterations` outer iterations from the neutral start -- a bounded sample (~20 s);
+    the sub-boxes are still small then, so the figure flatters the reference (profiles/r04_reference_256.json has the 16
+    iterations it takes to reach the mesh limit: 41-50 s each).  None when the binary is not there."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        import time_reference
+        r = time_reference.time_reference(mesh, iterations, threads=min(8, os.cpu_count() or 1), timeout=600)
+    except Exception as ex:  # noqa: BLE001 -- a baseline that cannot run is reported as absent, never fatal
+        sys.stderr.write(f"bench.py: reference at size not timed: {ex}\n")
+        return None
+    if r is None:
+        return None
+    t = sum(r["s_per_iteration"])
+    return {"value": mesh ** 3 * 8 * len(r["s_per_iteration"]) / t, "unit": "cell-updates/s", "cores": r["threads"], "kind": "reference",
+            "s_per_iteration": r["s_per_iteration"],
+            "sample": f"reference binary (flang -O2 -fopenmp), THIS workload's inputs ({mesh}^3, the same 8 sources), its first "
+                      f"{len(r['s_per_iteration'])} outer iterations from the neutral start in {t:.1f} s on this box's host cores "
+                      "(sub-boxes still small: an upper bound of its rate; at the mesh limit see cpu_baseline_reference_at_size)"}
+
+
 def launch_children(a):
     """`python bench.py --gpus N --launcher children`: start the N ranks as a CHILD torch.distributed.run and relay the one
     result line.  Runs before this process has imported torch or touched HIP (a process that has may not exec or be
@@ -522,6 +546,10 @@ def main():
             ref = cpu_baseline_reference()
             if ref is not None:
                 out["cpu_baseline_reference"] = ref
+            if headline:
+                ref = cpu_baseline_reference_at_size(n)
+                if ref is not None:
+                    out["cpu_baseline_reference_at_size_first_iterations"] = ref
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
