@@ -2,6 +2,7 @@
 transport because RCCL refuses two ranks on one device) share the sources, all-reduce the
 device-resident rate buffer through torch.distributed and replicate the chemistry -- the code path
 bench.py --gpus N runs over RCCL.  The two-rank result is compared with the single-rank one."""
+import json
 import os
 import sys
 
@@ -12,6 +13,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, collect_from_ranks, tap_case
 
 pytestmark = pytest.mark.gpu
+OUT = ROOT / "gpurun_out"
 
 
 def _worker(rank, world, port, q, pipelined=True):
@@ -360,3 +362,44 @@ def test_all_devices_of_the_node_rccl(pkg, gold):
         scale = np.maximum(np.abs(b[k]), 1e-300)
         assert np.max(np.abs(a[k] - b[k]) / scale) < 1e-12, k
     assert np.all(np.isfinite(a["xh_intermed"])) and np.max(np.abs(a["xh_intermed"] - b["xh_intermed"])) < 1e-6
+
+
+def _same_device_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import time
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    gold = lambda n: np.load(ROOT / "tests" / "golden" / n)
+    e, dt, _ = _engine(pkg, gold, 0)                     # BOTH ranks on device 0: RCCL refuses that
+    t0 = time.time()
+    try:
+        pkg.parallel.RcclComm(e, dist)
+        verdict = "ok"
+    except RuntimeError as ex:
+        verdict = "raised: " + str(ex)[:200]
+    q.put((rank, verdict, time.time() - t0, e.rccl_ranks()))
+    dist.barrier()
+    e.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_device_fail_together(pkg):
+    """Real RCCL, the failure it is known to give on a one-GPU box: two ranks whose contexts sit on the same device.
+    ncclCommInitRank refuses duplicate devices; what matters is HOW the refusal arrives -- on both ranks, as the same
+    RuntimeError of parallel.RcclComm, within the time-out, and with no communicator left behind (the state bench.py's
+    fall-back starts from).  A hang here would be a hang of the first multi-GPU launch."""
+    from conftest import collect_from_ranks
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34100 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_same_device_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (v, t, n) for r, v, t, n in collect_from_ranks(procs, q, nresults=2, timeout=240)}
+    assert got[0][0].startswith("raised") and got[1][0].startswith("raised"), got
+    assert got[0][2] == 0 and got[1][2] == 0, got
+    (OUT / "rccl_two_ranks_one_device.json").write_text(json.dumps({str(r): {"verdict": v, "seconds": t} for r, (v, t, _) in got.items()}, indent=1))
