@@ -46,13 +46,25 @@ def time_reference(mesh=256, iterations=2, threads=8, timeout=6 * 3600):
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib/llvm/lib:" + env.get("LD_LIBRARY_PATH", "")
     env["C2R_REF_STOP_AFTER"] = str(iterations)
     t0 = time.perf_counter()
-    r = subprocess.run([str(exe), "input"], cwd=run, env=env, capture_output=True, text=True, timeout=timeout)
+    # the clock's lines are passed on as they come (a long run must not look hung), and kept
+    proc = subprocess.Popen([str(exe), "input"], cwd=run, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stderr:
+        lines.append(line)
+        if "pass_timer" in line:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+        if time.perf_counter() - t0 > timeout:
+            proc.kill()
+            break
+    proc.wait()
+    err = "".join(lines)
     wall = time.perf_counter() - t0
     shutil.rmtree(run, ignore_errors=True)
-    its = [float(x) for x in re.findall(r"pass_timer: iteration \d+ took ([\d.]+) s", r.stderr)]
-    passes = [float(x) for x in re.findall(r"pass_timer: pass \d+ \(niter \d+\) took ([\d.]+) s", r.stderr)]
+    its = [float(x) for x in re.findall(r"pass_timer: iteration \d+ took ([\d.]+) s", err)]
+    passes = [float(x) for x in re.findall(r"pass_timer: pass \d+ \(niter \d+\) took ([\d.]+) s", err)]
     if not its:
-        sys.stderr.write(r.stderr[-2000:])
+        sys.stderr.write(err[-2000:])
         return None
     return {"binary": str(exe.relative_to(ROOT)), "what": f"the reference (flang -O2 -fopenmp), {n}^3 uniform density, the bench's 8 sources of 1e56 photons/s, "
             "isothermal 1e4 K, neutral start, dt = 1e7 yr, output streams off: its first outer iterations of evolve3D",
