@@ -34,6 +34,17 @@ def _case(rng):
                 opacity=float(rng.uniform(-4.5, -0.5)), seed=int(rng.integers(1 << 30)))
 
 
+def _progress(text):
+    """A long run keeps telling the GPU box that it is alive (a line per case in gpurun_out/fuzz_progress.log)."""
+    try:
+        out = Path(__file__).resolve().parent.parent / "gpurun_out"
+        out.mkdir(exist_ok=True)
+        with open(out / "fuzz_progress.log", "a") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+
+
 def test_random_cases_vs_oracle(pkg, orc):
     ncases = int(os.environ.get("C2R_FUZZ_CASES", "40"))
     master = np.random.default_rng(int(os.environ.get("C2R_FUZZ_SEED", "20261004")))
@@ -45,6 +56,7 @@ def test_random_cases_vs_oracle(pkg, orc):
              dict(mesh=(5, 9, 2), nsrc=2, iso=False, multi=True, lls=0, clump=True, batch=1, opacity=-2.0, seed=17)]
     for ic in range(ncases + len(fixed)):
         cs = fixed[ic] if ic < len(fixed) else _case(master)
+        _progress(f"case {ic}: {cs}")
         rng = np.random.default_rng(cs["seed"])
         n1, n2, n3 = cs["mesh"]
         nc = n1 * n2 * n3
@@ -167,6 +179,7 @@ def test_random_whole_evolve3d_vs_oracle(pkg, orc):
         st = orc.Step(mesh, dr, vol, zred, hp.H0, hp.Omega0, iso, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens, hp.reccoef(1.0e4))
         s = orc.State(st, xh, xhe, temp)
         tag = (ic, mesh, iso, nsrc)
+        _progress(f"evolve3D case {tag}: {niter} iterations on the device, the oracle next")
         assert orc.evolve3d(T, st, s, dt) == niter, tag
         assert ev.conv_flags == s.conv_flags, tag
         assert np.array_equal(mat.xh, s.xh) and np.array_equal(mat.xhe, s.xhe), tag
