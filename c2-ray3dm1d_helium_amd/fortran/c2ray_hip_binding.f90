@@ -374,6 +374,15 @@ module c2ray_hip
        type(c_ptr), value :: ctx
      end function c2r_comm_nranks
 
+     integer(c_int) function c2r_comm_available() bind(C, name="c2r_comm_available")
+       import :: c_int
+     end function c2r_comm_available
+
+     integer(c_int) function c2r_comm_rank(ctx) bind(C, name="c2r_comm_rank")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function c2r_comm_rank
+
      integer(c_int) function c2r_comm_kind(ctx) bind(C, name="c2r_comm_kind")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
@@ -455,6 +464,13 @@ module c2ray_hip
        type(c_ptr), value :: ctx
        integer(c_int), value :: on
      end function c2r_enable_timing
+
+     integer(c_int) function c2r_get_timing_device(ctx, idev, tm) bind(C, name="c2r_get_timing_device")
+       import :: c_int, c_ptr, c2r_timing
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: idev
+       type(c2r_timing), intent(out) :: tm
+     end function c2r_get_timing_device
 
      integer(c_int) function c2r_get_timing(ctx, tm) bind(C, name="c2r_get_timing")
        import :: c_int, c_ptr, c2r_timing

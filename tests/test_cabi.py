@@ -19,6 +19,14 @@ def test_header_and_binding_agree(pkg):
     assert declared_symbols() == sorted(pkg._lib.SYMBOLS)
 
 
+def test_fortran_binding_covers_the_header():
+    """fortran/c2ray_hip_binding.f90 -- the iso_c_binding view a Fortran host compiles -- binds every entry point the
+    header declares, and nothing else."""
+    f = (ROOT / "c2-ray3dm1d_helium_amd" / "fortran" / "c2ray_hip_binding.f90").read_text()
+    bound = sorted(set(re.findall(r'name="(c2r_[a-z0-9_]+)"', f)))
+    assert bound == declared_symbols()
+
+
 def test_library_exports_every_declared_symbol(pkg):
     lib = C.CDLL(str(pkg.build()))
     for name in declared_symbols():
