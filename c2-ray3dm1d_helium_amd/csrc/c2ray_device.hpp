@@ -453,7 +453,7 @@ inline bool any_lane(bool p) { return p; }
 // are used by the band loop.  [0] band bodies a wave ran, [1] lanes alive in them, [2] bands skipped by the
 // whole wave, [3] source bodies a wave ran, [4] lanes inside the sub-box in them, [5] sources skipped by the wave;
 // [6..8] the same triple for div_by_vol's doubt branch, [9..11] for its true divisions, [12..14] for the near-1 path
-// of the log.
+// of the log, [21..23] for optically thin bands (photo_lookuptable's second branch).
 #if defined(C2R_RATES_COUNT)
 extern __device__ unsigned long long c2r_rates_cnt[64 * 24];
 #endif
@@ -756,6 +756,7 @@ C2R_HD void band_sed(const BD &bd, const double *photo_thick, const double *phot
   const double sc_HI = B.sc_HI, sc_HeI = B.sc_HeI, sc_HeII = B.sc_HeII;
   (void)sHeI; (void)sHeII; (void)sc_HI; (void)sc_HeI; (void)sc_HeII; (void)hthick;
   // photo_lookuptable body
+  C2R_COUNT_LANES(21, !thick); // [21..23] waves with an optically thin lane in this band, such lanes, waves without
   {
     const double *tk = photo_thick + (size_t)b * NTAUP;
     double phi_in, phi_out, phi_all;

@@ -79,6 +79,7 @@ def lane_census(pkg):
             "div_redo_waves": int(out[9]), "div_redo_lanes": int(out[10]), "log_near1_waves": int(out[12]), "log_near1_lanes": int(out[13]),
             "log_table_only_waves": int(out[14]),
             "log_near1_both_args_waves": int(out[15]), "log_near1_both_args_lanes": int(out[16]), "log_near1_two_blocks_waves": int(out[18]),
+            "thin_band_waves": int(out[21]), "thin_band_lanes": int(out[22]),
             "source_bodies_per_wave": srcs, "source_lane_fill": inbox / (64.0 * srcs) if srcs else None, "sources_skipped_by_wave": srcskip}
 
 
@@ -102,6 +103,8 @@ def main():
                     help="play ALL --ranks ranks one after another on this GPU in every iteration (their rates add up in the one set of "
                          "rate grids, then one global pass): the full problem's ionisation history, and every rank's share of "
                          "each pass timed separately -- what decides the scaling of the sharded run")
+    ap.add_argument("--calls", type=int, default=1, help="with --headline --neutral: evolve3D calls (time steps) in a row, each to convergence")
+    ap.add_argument("--neutral", action="store_true", help="with --headline: the reference's neutral start instead of the pre-ionised bench state")
     ap.add_argument("--lane-census", action="store_true",
                     help="library built with -DC2R_RATES_COUNT: per iteration, how well k_rates' band loop fills its lanes")
     a = ap.parse_args()
@@ -114,7 +117,7 @@ def main():
     if a.headline:
         import bench
         a.sources, a.ranks, a.rank = 8, 1, 0
-        mat, grid, src, cosmo = bench.config3_inputs(pkg, n, 8, heating=a.heating)
+        mat, grid, src, cosmo = bench.config3_inputs(pkg, n, 8, heating=a.heating, neutral=a.neutral)
     else:
         mat, grid, src, cosmo = config4_inputs(pkg, n, a.sources, heating=a.heating, corr_index=a.correlated)
     tables = pkg.RadiationTables.load()
@@ -143,7 +146,22 @@ def main():
     hist = []
     t_all = time.perf_counter()
     niter, conv = 0, n ** 3
-    while not (conv < conv_criterion and niter > 1) and niter < a.max_iter:
+    calls_left = a.calls
+    call_no = 1
+    while True:
+        if (conv < conv_criterion and niter > 1) or niter >= a.max_iter:
+            calls_left -= 1
+            if calls_left <= 0:
+                break
+            # the next time step: end this one, hand the state over as evolve3D's caller would, begin anew
+            e.end_step()
+            e.download_state(mat)
+            e.set_step(mat, grid, cosmo)
+            e.set_sources(src)
+            e.upload_state(mat)
+            e.begin_step()
+            niter, conv = 0, n ** 3
+            call_no += 1
         niter += 1
         t0 = time.perf_counter()
         e.set_rates_to_zero()
@@ -162,7 +180,7 @@ def main():
         t2 = time.perf_counter()
         tm = e.timing()
         census = lane_census(pkg) if a.lane_census else None
-        hist.append({"iter": niter, "pass_ms": 1e3 * (t1 - t0), "chem_ms": 1e3 * (t2 - t1), "sweep_kernel_ms": tm.sweep_ms,
+        hist.append({"call": call_no, "iter": niter, "pass_ms": 1e3 * (t1 - t0), "chem_ms": 1e3 * (t2 - t1), "sweep_kernel_ms": tm.sweep_ms,
                      "rates_kernel_ms": tm.rates_ms, "cells_swept": int(tm.cells_swept), "sweep_launches": tm.sweep_launches,
                      "rates_launches": tm.rates_launches, "nonconv": int(conv), "sum_nbox": int(e.get_loss()[1])})
         if census:
