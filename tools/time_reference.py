@@ -49,15 +49,23 @@ def time_reference(mesh=256, iterations=2, threads=8, timeout=6 * 3600):
     # the clock's lines are passed on as they come (a long run must not look hung), and kept
     proc = subprocess.Popen([str(exe), "input"], cwd=run, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     lines = []
-    for line in proc.stderr:
-        lines.append(line)
-        if "pass_timer" in line:
-            sys.stderr.write(line)
-            sys.stderr.flush()
-        if time.perf_counter() - t0 > timeout:
-            proc.kill()
-            break
-    proc.wait()
+
+    def reader():
+        for line in proc.stderr:
+            lines.append(line)
+            if "pass_timer" in line:
+                sys.stderr.write(line)
+                sys.stderr.flush()
+
+    import threading
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    try:
+        proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:      # a run that stopped printing is ended here, not waited for
+        proc.kill()
+        proc.wait()
+    th.join(timeout=10)
     err = "".join(lines)
     wall = time.perf_counter() - t0
     shutil.rmtree(run, ignore_errors=True)
