@@ -106,6 +106,7 @@ SYMBOLS = {
     "c2r_comm_rank": (C.c_int, [C.c_void_p]),
     "c2r_comm_nranks": (C.c_int, [C.c_void_p]),
     "c2r_comm_kind": (C.c_int, [C.c_void_p]),
+    "c2r_comm_library": (C.c_int, [C.c_char_p, C.c_int]),
     "c2r_allreduce_rates": (C.c_int, [C.c_void_p]),
     "c2r_pass_allreduce_chemistry": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _ip]),
     "c2r_iteration": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(IterationReport)]),

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -1488,6 +1489,9 @@ struct c2r_ctx {
   // sum over ranks (c2ray_comm.inc): kind 0 none, 1 RCCL, 2 in-process sum for replicas that share a device
   int comm_kind = 0, comm_rank = 0, comm_nranks = 1;
   void *comm = nullptr;            // ncclComm_t
+  bool comm_broken = false;        // the communicator was aborted after an error inside a collective phase (c2ray_comm.inc)
+  std::string comm_broken_why;
+  long long slab_passes = 0;       // slab-wise passes this context has run (C2R_FAULT_INJECT counts them)
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_comm_a = nullptr, ev_comm_b = nullptr;
   std::vector<hipEvent_t> ev_sum;  // slab s of the rate grids is summed over the ranks
@@ -1662,6 +1666,35 @@ static int fail(c2r_ctx *c, const char *fmt, ...) {
     hipError_t e_ = (call);                                                                         \
     if (e_ != hipSuccess) return fail(c, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// hipStreamSynchronize -- with a deadline where the stream may be waiting for OTHER RANKS (an RCCL communicator of more
+// than one rank: the chemistry of a slab is queued behind the sum of that slab, the sum waits for every rank).  A rank
+// that died, or returned from its pass with an error, never issues its share of the sum, and a plain synchronisation
+// would then wait for ever.  C2R_COMM_TIMEOUT_S: seconds to wait (default 1800; 0: for ever).  The caller turns the
+// error into an abort of the communicator (with_comm_abort), which is what ends the waiting kernels.
+static int sync_stream(c2r_ctx *c, hipStream_t s, const char *what) {
+  double limit = 0.0;
+  if (c->comm_kind == 1 && c->comm_nranks > 1) {
+    const char *e = getenv("C2R_COMM_TIMEOUT_S");
+    limit = e ? atof(e) : 1800.0;
+  }
+  if (limit <= 0.0) {
+    HIPCHK(c, hipStreamSynchronize(s));
+    return 0;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; spin++) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return 0;
+    if (e != hipErrorNotReady) return fail(c, "hipStreamQuery failed while waiting for %s: %s", what, hipGetErrorString(e));
+    if (spin < 4096) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited > limit)
+      return fail(c, "rank %d of %d waited %.0f s for %s: a peer rank has not issued its share of the sum over the ranks "
+                  "(C2R_COMM_TIMEOUT_S)", c->comm_rank, c->comm_nranks, waited, what);
+  }
+}
 
 // a context made by c2r_create_multi drives further devices through `replicas` (plain one-device contexts)
 template <class F>
@@ -3274,8 +3307,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
 
 static int pass_finish(c2r_ctx *c) {
   if (!c->pass_open) return 0;
-  HIPCHK(c, hipStreamSynchronize(c->stream2));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sync_stream(c, c->stream2, "the pass (rates stream)")) return 1;
+  if (sync_stream(c, c->stream, "the pass")) return 1;
   c->set_busy[0] = c->set_busy[1] = false;
   // photon_loss(1) += photon_loss_src ; sum_nbox += nbox  (evolve_source.F90:233-236): batch by batch, source by
   // source, now that the losses the rates launches left behind have arrived
@@ -3291,7 +3324,7 @@ static int pass_finish(c2r_ctx *c) {
   std::memcpy(c->h_tail, c->photon_loss, sizeof c->photon_loss);
   c->h_tail[C2R_NFREQ] = (double)c->sum_nbox;
   HIPCHK(c, hipMemcpyAsync(c->d_rates + 4 * c->g.ncell, c->h_tail, sizeof(double) * (C2R_NFREQ + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sync_stream(c, c->stream, "the pass")) return 1;
   const std::vector<hipEvent_t> &tev = c->pass_tev;
   for (size_t i = 0; i + 3 < tev.size(); i += 4) {
     float ms = 0;
@@ -3564,7 +3597,7 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     for (int t = 1; t < CHEM_TIERS; t++) {
       int n = 0;
       HIPCHK(c, hipMemcpyAsync(&n, c->d_chemctl + cur, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (sync_stream(c, c->stream, "a tier of the global pass")) return 1;
       if (chem_log) {
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "c2ray_hip: heating pass, tier %d (ceiling %lld sub-steps) done after %.1f ms: %d cells deferred\n", t - 1,
@@ -3587,7 +3620,7 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     // (a pass whose cells all need some tens of sub-steps would otherwise do 16 of them in vain for every cell)
     int hist[CHEM_HIST + 2];
     HIPCHK(c, hipMemcpyAsync(hist, c->d_chemctl + 2, sizeof hist, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sync_stream(c, c->stream, "the global pass")) return 1;
     {
       long long total = 0, acc = 0;
       for (int b = 0; b < CHEM_HIST; b++) total += hist[b];
@@ -3639,7 +3672,7 @@ extern "C" int c2r_global_pass_finish(c2r_ctx *c, int *conv_flag) {
     c->want_iter_stats = false;
   }
   HIPCHK(c, hipMemcpyAsync(c->h_conv, c->d_conv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (sync_stream(c, c->stream, "the global pass")) return 1;
   if (c->timing) {
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3], c->ev[4]));

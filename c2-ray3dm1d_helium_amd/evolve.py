@@ -173,6 +173,15 @@ class HipEngine:
         lib = _lib.load()
         return None if lib.c2r_comm_available() == 0 else lib.c2r_create_error().decode()
 
+    @staticmethod
+    def comm_library():
+        """Path of the library that carries the sums over ranks (c2r_comm_library); raises when none can be loaded."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(1024)
+        if lib.c2r_comm_library(buf, 1024) != 0:
+            raise C2RayHipError(lib.c2r_create_error().decode())
+        return buf.value.decode()
+
     def comm_destroy(self):
         self._chk(self.lib.c2r_comm_destroy(self.h))
 

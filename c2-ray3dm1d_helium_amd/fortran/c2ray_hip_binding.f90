@@ -388,6 +388,12 @@ module c2ray_hip
        type(c_ptr), value :: ctx
      end function c2r_comm_kind
 
+     integer(c_int) function c2r_comm_library(out, capacity) bind(C, name="c2r_comm_library")
+       import :: c_int, c_char
+       character(kind=c_char), dimension(*) :: out
+       integer(c_int), value :: capacity
+     end function c2r_comm_library
+
      integer(c_int) function c2r_allreduce_rates(ctx) bind(C, name="c2r_allreduce_rates")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

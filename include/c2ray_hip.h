@@ -272,6 +272,17 @@ int c2r_comm_nranks(const c2r_ctx *ctx);
  * 1 RCCL (ncclAllReduce), 2 the in-process sum of replicas that share a device (rehearsal mode of
  * c2r_comm_init_local).  A harness reports c2r_comm_nranks as "ranks RCCL saw" only when this is 1. */
 int c2r_comm_kind(const c2r_ctx *ctx);
+/* Path of the library whose ncclAllReduce carries the sums (librccl.so.1 of the loader's path, or the file named by
+ * the environment variable C2R_RCCL_LIBRARY), "" when none could be loaded (non-zero return, reason in
+ * c2r_create_error()).  A harness prints it next to its result: a sum carried by anything but RCCL is not an RCCL result. */
+int c2r_comm_library(char *out, int capacity);
+/* Errors while a communicator is in use (the reference has none: its ranks log, go on and meet again at the next
+ * MPI_ALLREDUCE, evolve.F90:177-181,523-538; its drop-in host ends the job with MPI_ABORT).  c2r_allreduce_rates,
+ * c2r_pass_allreduce_chemistry, c2r_iteration and c2r_evolve3d ABORT the context's RCCL communicators (ncclCommAbort)
+ * before they return an error: nothing of this process is left waiting in a sum that cannot complete, every later
+ * collective call on the context fails at once, and the host is expected to exit non-zero so that its launcher ends the
+ * other ranks.  A rank whose peer never issues its share of a sum does not wait for ever either: after
+ * C2R_COMM_TIMEOUT_S seconds (environment; default 1800, 0 = no limit) its wait ends with an error and the same abort. */
 /* mpi_accumulate_grid_quantities (evolve.F90:505-548) after c2r_pass_sources: the whole buffer in one
  * all-reduce; afterwards c2r_get_loss / c2r_download_rates return the summed photon_loss and sum_nbox_all.
  * A no-op on a single rank without communicator.  On a multi-device context c2r_pass_sources(first, stride)

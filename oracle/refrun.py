@@ -28,17 +28,19 @@ REFDIR = HERE / "_ref"
 _KINDS = {1: np.int32, 2: np.float32, 3: np.float64}
 
 
-def read_records(path) -> dict:
-    """Read a tap dump (see oracle/probe/evolve_tap.f90 for the record layout)."""
+def read_records(path, mmap=False) -> dict:
+    """Read a tap dump (see oracle/probe/evolve_tap.f90 for the record layout).  mmap: arrays are read-only views of
+    the memory-mapped file (dumps of a 256^3 run are GBs)."""
     out = {}
-    data = Path(path).read_bytes()
+    data = np.memmap(path, dtype=np.uint8, mode="r") if mmap else Path(path).read_bytes()
     off = 0
     while off < len(data):
-        name = data[off:off + 16].decode().strip()
-        kind, count = struct.unpack_from("<iq", data, off + 16)
+        name = bytes(data[off:off + 16]).decode().strip()
+        kind, count = struct.unpack_from("<iq", bytes(data[off + 16:off + 28]), 0)
         off += 28
         dt = np.dtype(_KINDS[kind])
-        out[name] = np.frombuffer(data, dtype=dt, count=count, offset=off).copy()
+        a = np.frombuffer(data, dtype=dt, count=count, offset=off)
+        out[name] = a if mmap else a.copy()
         off += count * dt.itemsize
     return out
 
