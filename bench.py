@@ -361,6 +361,14 @@ def main():
             comm = pkg.parallel.TorchComm(dist.new_group(backend="nccl"))
             transport = f"FALL-BACK: torch.distributed nccl (= RCCL) all-reduce of the rate grids, slab-wise, overlapped; the library's own communicator failed: {ex}"
     rccl_ranks = e.rccl_ranks()
+    rccl_library = None
+    if rccl_ranks:
+        # what carried the sums: the loader's librccl -- or whatever C2R_RCCL_LIBRARY names (the one-device stand-in of
+        # tests/fake_rccl.hip rehearses the N-rank control flow on a one-GPU box); only the former is an RCCL result
+        rccl_library = pkg.HipEngine.comm_library()
+        if not os.path.basename(rccl_library).startswith("librccl"):
+            transport = f"STAND-IN for RCCL ({rccl_library}, C2R_RCCL_LIBRARY) -- NOT an RCCL result: {transport}"
+            rccl_ranks = 0
     dt = 1.0e7 * pkg.hostphys.YEAR
     e.begin_step()
 
@@ -436,6 +444,7 @@ def main():
             # ranks of the RCCL communicator INSIDE the library that summed the rate grids (c2r_comm_nranks; 0: one rank
             # without communicator, a fall-back transport, or replicas sharing a device)
             "rccl_ranks": rccl_ranks,
+            "rccl_library": rccl_library,
             "config": {"workload": (f"BASELINE configs[3]: {n}^3 log-normal density, {total_src} sources dealt over {world} GPU(s) "
                                     f"({per_gpu} on rank 0), neutral start, {'heating' if heating else 'isothermal 1e4 K'}, one evolve3D "
                                     f"outer iteration per step (the state evolves from step to step)") if cfg4 else

@@ -7,8 +7,10 @@
 //   rates          k_rates         all cells x all sources of the batch, no dependencies:
 //                                  photoion_rates + accumulation into the rate grids in source order
 //                                  (evolve0D, second half)
-//   boundary loss  k_loss_exact    full photon loss through a sub-box surface from the stored columns, when
-//                                  the 1/16 sample taken inside the sweep did not decide the while-test
+//   boundary loss  k_loss_probe_rounds  a lower bound of the photon loss through a sub-box surface from a sample of the
+//                                  stored columns (decides "this source goes on" for several rounds in one launch);
+//                  k_loss, k_loss_finish   the full, block-ordered sum where the bound does not decide or the loss is kept;
+//                  k_loss_stored   the kept loss of a final round, left behind by k_rates in the unused N_in(HI) slots
 //   chemistry      k_chemistry     evolve0D_global / do_chemistry / doric / thermal per cell
 //   statistics     k_state_sums, k_total_rates, k_stat_finish   the grid sums of photonstatistics.f90
 //   tables         k_build_tables  spec_integration: the photo-ionisation / heating tables of one SED
@@ -647,7 +649,7 @@ template <bool HEAT, bool MULTI>
 __global__ void __launch_bounds__(BLOCK, MULTI ? (HEAT ? C2R_RATES_WAVES_HEAT_MULTI : 4) : (HEAT ? C2R_RATES_WAVES_HEAT : C2R_RATES_WAVES_ISO))
 k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const double *__restrict__ ndens,
         const double *__restrict__ xh_av, const double *__restrict__ xhe_av,
-        const BandData *__restrict__ bd, SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles,
+        const BandDataByRow *__restrict__ bdr, SedSet ss, double *__restrict__ rates, const int *__restrict__ tiles,
         const int *__restrict__ tile_ptr, const int *__restrict__ tile_src, int tile_base, int fresh) {
   const size_t nc = g.ncell;
   // One block = a tile of 8 x 8 x 4 cells, one wave = a 4 x 4 x 4 cube of it.  Neighbouring cells see
@@ -672,6 +674,9 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
   s_logtab[threadIdx.x] = gm::log_table()[threadIdx.x];
 #endif
   __syncthreads();
+  // the band data as uploaded (a BandDataByRow: the plain arrays and, behind them, the same numbers band by band); a kernel
+  // chooses its reading of them by the TYPE it hands down -- the base for the array form (an upcast, not a reinterpretation)
+  const BandData *const bd = bdr;
   // two polynomial constants of the log held in vector registers for the whole kernel (gm::LogPins): -0.25 ms per
   // launch in the isothermal kernel; the heating kernels, which have no registers to spare, lose 2.7 ms with them
   gm::LogPins pins_ = {0.0, 0.0};
@@ -817,7 +822,7 @@ k_rates(Grid g, const SrcDev *__restrict__ src, int nsrc, StepScalars sc, const 
         if (MULTI) {
           const double nf[NSED] = {S.nflux, S.nflux_sed[0], S.nflux_sed[1]};
           if constexpr (HEAT && (C2R_RATES_BAND_ROWS)) // this kernel reads cross sections and factors band by band (BandDataByRow)
-            photoion_rates_multi<HEAT>(*static_cast<const BandDataByRow *>(bd), ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII,
+            photoion_rates_multi<HEAT>(*bdr, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII,
                                        vol_ph, nf, ric, o, &s_logtab[0], pins);
           else
             photoion_rates_multi<HEAT>(*bd, ss, cin_HI, cout_HI, cin_HeI, cout_HeI, cin_HeII, cout_HeII, vol_ph, nf, ric, o, &s_logtab[0], pins);
@@ -1503,9 +1508,9 @@ struct c2r_ctx {
   // the heating tables as the kernels read them, interleaved by band (c2ray_device.hpp heat_interleave): [sed][thick, thin];
   // the column-wise copies above (and d_sed_tab[][2..3]) stay for c2r_download_tables and band_tau_zero
   double *d_heat_woven[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  BandData *d_bands = nullptr;
-  BandDataByRow h_bands{};         // host copy (tau_zero is refreshed whenever a table set changes); what d_bands holds: a BandData
-                                   // whose band-by-band copy is filled in, which the three-SED heating kernel reads as BandDataByRow
+  BandDataByRow *d_bands = nullptr;
+  BandDataByRow h_bands{};         // host copy (tau_zero is refreshed whenever a table set changes); d_bands is its upload: the
+                                   // other kernels take it as its base BandData, the three-SED heating kernel as what it is
   bool have_tables = false, have_heat_tables = false, have_bands = false, have_fvec = false;
   int bb_upper = 0;
   double *d_cool = nullptr;
@@ -1912,7 +1917,7 @@ extern "C" int c2r_create(c2r_ctx **out, int device, const int mesh[3]) {
   CR(hipHostMalloc(&c->h_tail, sizeof(double) * (C2R_NFREQ + 1)));
   CR(hipMalloc(&c->d_conv, sizeof(int)));
   CR(hipHostMalloc(&c->h_conv, sizeof(int)));
-  CR(hipMalloc(&c->d_bands, sizeof(BandData)));
+  CR(hipMalloc(&c->d_bands, sizeof(BandDataByRow)));
   for (auto &ev : c->ev) CR(hipEventCreate(&ev));
 #undef CR
   *out = c;
@@ -2047,7 +2052,7 @@ static int refresh_tau_zero(c2r_ctx *c, int sed) {
   }
   if (c->have_bands) {
     band_rows_fill(c->h_bands);
-    HIPCHK(c, hipMemcpy(c->d_bands, &c->h_bands, sizeof(BandData), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_bands, &c->h_bands, sizeof(BandDataByRow), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -2132,10 +2137,24 @@ static int set_cooling_one(c2r_ctx *c, const double *cool, double mintemp, doubl
 // The lists of the heating tiers (cells dropped by a launch, redone by the next) and their counters: made when a step
 // is declared non-isothermal (c2r_set_step), zeroed on the stream their first user follows.
 static int alloc_heating_lists(c2r_ctx *c) {
-  if (c->isothermal || c->d_defer[0]) return 0;
-  for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell));
-  HIPCHK(c, hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST))); // two list counts, then the histogram
-  HIPCHK(c, hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST), c->stream));
+  if (c->isothermal || (c->d_defer[0] && c->d_defer[1] && c->d_chemctl)) return 0;
+  // all three or none: an allocation that fails half-way (out of memory) gives back what it got, so that the next
+  // c2r_set_step tries again instead of finding "the lists exist" with a null pointer among them (round-4 ADVICE)
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; k++)
+    if (!c->d_defer[k]) e = hipMalloc(&c->d_defer[k], sizeof(int) * c->g.ncell);
+  if (e == hipSuccess && !c->d_chemctl) e = hipMalloc(&c->d_chemctl, sizeof(int) * (4 + CHEM_HIST)); // two list counts, then the histogram
+  if (e == hipSuccess) e = hipMemsetAsync(c->d_chemctl, 0, sizeof(int) * (4 + CHEM_HIST), c->stream);
+  if (e != hipSuccess) {
+    for (int k = 0; k < 2; k++) {
+      if (c->d_defer[k]) (void)hipFree(c->d_defer[k]);
+      c->d_defer[k] = nullptr;
+    }
+    if (c->d_chemctl) (void)hipFree(c->d_chemctl);
+    c->d_chemctl = nullptr;
+    (void)hipGetLastError();
+    return fail(c, "c2r_set_step: the lists of the heating global pass could not be allocated: %s", hipGetErrorString(e));
+  }
   return 0;
 }
 
@@ -2154,7 +2173,6 @@ static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], dou
   c->sc.temper_val = temper_val;
   std::memcpy(&c->sc.rc, reccoef, sizeof(double) * 12);
   c->zred = zred; c->H0 = H0; c->Omega0 = Omega0;
-  c->isothermal = isothermal ? 1 : 0;
   c->have_step = true;
   c->packed_valid = c->transposed_valid = false; // ndens may have changed
   return 0;
@@ -3460,7 +3478,8 @@ static int fold_chemistry_counters(c2r_ctx *c, hipStream_t st) {
 // the c2r_set_step that declared the step non-isothermal (round 3 allocated both here, inside the first pass).
 static int ensure_chemistry_buffers(c2r_ctx *c) {
   if (!c->d_chemspread) return fail(c, "the chemistry counters are missing (c2r_create did not finish?)");
-  if (!c->isothermal && !c->d_defer[0]) return fail(c, "a non-isothermal pass before c2r_set_step declared the step non-isothermal");
+  if (!c->isothermal && !(c->d_defer[0] && c->d_defer[1] && c->d_chemctl))
+    return fail(c, "a non-isothermal pass before c2r_set_step declared the step non-isothermal (or its lists could not be allocated)");
   return 0;
 }
 

@@ -112,9 +112,15 @@ class RcclComm:
         """Collective over `dist`: either every rank leaves with a communicator or every rank raises the same
         error (and holds none) -- a rank that failed alone would leave the others waiting inside the collective
         ncclCommInitRank, or inside the broadcast of the id.  Three agreements, each over torch.distributed:
-        (1) every rank can load RCCL (c2r_comm_available), (2) rank 0 obtained the id (the error text travels in
-        its place), (3) every rank's c2r_comm_init succeeded.  fail_on_ranks: ranks that pretend step (1) failed
-        (rehearsal of the fall-back in bench.py and tests/test_host_logic.py)."""
+        (1) every rank can load RCCL (c2r_comm_available) AND meets c2r_comm_init's local preconditions (its context has
+        no communicator yet) -- everything a rank can know on its own is settled before the collective call, (2) rank 0
+        obtained the id (the error text travels in its place), (3) every rank's c2r_comm_init succeeded.
+        What (3) cannot cover: a rank that fails INSIDE ncclCommInitRank (a device error) while its peers are already
+        blocked in the same collective -- they never reach the agreement.  For that window c2r_comm_init runs under a
+        watchdog: a rank whose call has not returned after C2R_COMM_INIT_TIMEOUT_S seconds (default 600; 0: no limit)
+        says so on stderr and EXITS the process with status 3, so that the launcher (torch.distributed.run, mpirun) ends
+        the job instead of leaving it hung.  fail_on_ranks: ranks that pretend step (1) failed (rehearsal of the
+        fall-back in bench.py and tests/test_host_logic.py)."""
         self.engine = engine
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
@@ -130,6 +136,8 @@ class RcclComm:
             return next((f"rank {r}: {e}" for r, e in enumerate(errs) if e is not None), None)
 
         err = "forced failure (rehearsal)" if self.rank in tuple(fail_on_ranks) else type(engine).comm_available()
+        if err is None and engine.comm_size() > 1:
+            err = "the context already has a communicator"
         err = agree(err)
         if err is not None:
             raise RuntimeError(f"RCCL is not usable on every rank: {err}")
@@ -143,16 +151,41 @@ class RcclComm:
             dist.broadcast_object_list(box, src=0)
         if box[0][0] != "id":
             raise RuntimeError(f"rank 0 could not obtain the RCCL id: {box[0][1]}")
-        err = None
-        try:
-            engine.comm_init(self.rank, self.size, box[0][1])
-        except Exception as ex:  # noqa: BLE001
-            err = str(ex)
+        err = self._init_with_watchdog(engine, box[0][1])
         all_err = agree(err)
         if all_err is not None:
             if err is None:
                 engine.comm_destroy()
             raise RuntimeError(f"c2r_comm_init failed: {all_err}")
+
+    def _init_with_watchdog(self, engine, unique_id):
+        """c2r_comm_init; returns the error text or None.  Does not return at all when the call outlives the time-out."""
+        import os
+        import sys
+        import threading
+        limit = float(os.environ.get("C2R_COMM_INIT_TIMEOUT_S", "600"))
+        out = {}
+
+        def call():
+            try:
+                engine.comm_init(self.rank, self.size, unique_id)
+                out["err"] = None
+            except Exception as ex:  # noqa: BLE001
+                out["err"] = str(ex)
+
+        if limit <= 0 or self.size == 1:
+            call()
+            return out["err"]
+        th = threading.Thread(target=call, daemon=True)
+        th.start()
+        th.join(limit)
+        if th.is_alive():
+            sys.stderr.write(f"c2ray_hip: rank {self.rank} of {self.size}: c2r_comm_init (ncclCommInitRank) has not returned after "
+                             f"{limit:.0f} s -- a peer rank is missing or failed inside the collective; exiting so that the launcher "
+                             "ends the job (C2R_COMM_INIT_TIMEOUT_S)\n")
+            sys.stderr.flush()
+            os._exit(3)
+        return out["err"]
 
     def allreduce_rates(self, engine=None):
         self.engine.allreduce_rates()

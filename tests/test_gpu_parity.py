@@ -1173,3 +1173,57 @@ def test_fast_sweep_equals_the_general_sweep(pkg, tmp_path):
     assert np.count_nonzero(res["fast"]["h1"]) > 0.9 * 128 ** 3        # the boxes do fill the mesh
     for k in res["fast"].files:
         assert np.array_equal(res["fast"][k], res["generic"][k]), k
+
+
+_CHEM_SNIPPET = r'''
+import sys, numpy as np
+sys.path.insert(0, "{root}")
+import __graft_entry__ as ge
+pkg = ge.load_package()
+hp = pkg.hostphys
+out = {{}}
+for tag, mesh, iso in (("a", (8, 4, 4), True), ("b", (8, 4, 4), False), ("c", (16, 8, 12), True), ("d", (24, 12, 8), False), ("e", (32, 32, 32), False)):
+    rng = np.random.default_rng(3 + mesh[0] + mesh[2])
+    zred = 9.0
+    dr, vol = hp.test_grid(16, zred)
+    nc = int(np.prod(mesh))
+    ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc))
+    x = 10.0 ** rng.uniform(-5, -0.5, nc)
+    xh = np.concatenate([1.0 - x, x]); xhe = np.concatenate([1.0 - x, 0.7 * x, 0.3 * x])
+    temp = None if iso else np.tile((1e4 * np.exp(rng.normal(0, 0.2, nc))).astype(np.float32), 3)
+    srcpos = np.array([[1, mesh[1], mesh[2] // 2], [mesh[0] // 2, 3, mesh[2]]], dtype=np.int32)
+    mat = pkg.Material(ndens, xh, xhe, temp, iso, 1.0e4, 1.0, hp.reccoef(1.0e4))
+    e = pkg.HipEngine(mesh, 0)
+    e.set_tables(pkg.RadiationTables.load()); e.set_step(mat, pkg.GridProps(mesh, dr, vol), pkg.Cosmology(zred, hp.H0, hp.Omega0))
+    e.set_sources(pkg.SourceProps(srcpos, np.array([3.0e7, 8.0e6]), 1.0e48)); e.upload_state(mat)
+    e.begin_step()
+    conv = []
+    for it in range(3):
+        e.set_rates_to_zero(); e.pass_sources(1, 1); conv.append(e.global_pass(3.0e6 * hp.YEAR))
+    for k, v in e.download_iter_state().items():
+        out[tag + "_" + k] = v
+    if not iso:
+        e.download_state(mat); out[tag + "_temperature"] = mat.temperature_grid
+    out[tag + "_conv"] = np.array(conv)
+    e.close()
+np.savez("{out}", **out)
+'''
+
+
+def test_chemistry_wave_shapes_change_nothing(pkg, tmp_path):
+    """k_chemistry's waves as rows of 64 cells, as 4 x 4 x 4 cubes and as 8 x 4 x 2 bricks (C2R_CHEM_CUBES = 0 / 1 / 2, read once
+    per process: each in a process of its own; the default switches between rows and bricks by the last pass's non-converged
+    count): three outer iterations on meshes from a single brick pair (8 x 4 x 4) to 32^3, isothermal and with heating (whose
+    repacked tiers always take rows) -- iteration state, temperatures and non-converged counts bit for bit (round-4 ADVICE)."""
+    import subprocess
+    res = {}
+    for tag, env in (("default", {}), ("rows", {"C2R_CHEM_CUBES": "0"}), ("cubes", {"C2R_CHEM_CUBES": "1"}), ("bricks", {"C2R_CHEM_CUBES": "2"})):
+        out = tmp_path / f"chem_{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", _CHEM_SNIPPET.format(root=str(ROOT), out=str(out))], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    assert int(res["rows"]["e_conv"][0]) > 0
+    for tag in ("default", "cubes", "bricks"):
+        for k in res["rows"].files:
+            assert np.array_equal(res["rows"][k], res[tag][k]), (tag, k)

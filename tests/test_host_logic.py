@@ -158,10 +158,16 @@ class _FakeRcclEngine:
             raise RuntimeError("ncclGetUniqueId failed (injected)")
         return b"x" * 128
 
+    def comm_size(self):
+        return 2 if _FakeRcclEngine.mode == "has_comm_on_1" and _FakeRcclEngine.rank == 1 else 1
+
     def comm_init(self, rank, size, uid):
         assert uid == b"x" * 128
         if _FakeRcclEngine.mode == "init_fails_on_1" and rank == 1:
             raise RuntimeError("ncclCommInitRank failed (injected)")
+        if _FakeRcclEngine.mode == "init_hangs_on_0" and rank == 0:
+            import time
+            time.sleep(3600)          # a collective whose peer never arrives
         self.log.append("init")
 
     def comm_destroy(self):
@@ -185,7 +191,7 @@ def _comm_setup_worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ok", "forced_on_0", "unavailable_on_1", "id_fails", "init_fails_on_1"])
+@pytest.mark.parametrize("mode", ["ok", "forced_on_0", "unavailable_on_1", "has_comm_on_1", "id_fails", "init_fails_on_1"])
 def test_rccl_comm_setup_is_collective(mode):
     """Round-3 ADVICE: a failure on one rank only (rank 0 cannot obtain the id; one rank cannot load RCCL or fails in
     c2r_comm_init) left the other ranks waiting inside a collective.  Now both ranks return within the time-out,
@@ -205,3 +211,27 @@ def test_rccl_comm_setup_is_collective(mode):
             assert got[0][1] == ["init", "destroy"] and got[1][1] == []
         else:
             assert got[0][1] == [] and got[1][1] == []
+
+
+def test_rccl_comm_init_watchdog_ends_the_process(monkeypatch):
+    """Round-4 ADVICE: a rank stuck INSIDE the collective c2r_comm_init (its peer failed in ncclCommInitRank, or never came)
+    cannot reach RcclComm's third agreement.  Its watchdog says so and exits the process with status 3 after
+    C2R_COMM_INIT_TIMEOUT_S, which is what makes a launcher end the job; here the test plays the launcher."""
+    import time
+    monkeypatch.setenv("C2R_COMM_INIT_TIMEOUT_S", "3")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_comm_setup_worker, args=(r, 2, port, "init_hangs_on_0", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    t0 = time.time()
+    procs[0].join(timeout=90)
+    try:
+        assert procs[0].exitcode == 3, procs[0].exitcode
+        assert time.time() - t0 < 80
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+            p.join(timeout=30)

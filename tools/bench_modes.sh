@@ -9,6 +9,11 @@ run default python bench.py --steps 20 --warmup 3 --no-cpu-baseline
 run one_process python bench.py --gpus 1 --one-process --steps 20 --warmup 3 --no-cpu-baseline
 C2R_BENCH_FORCE_COMM=1 run force_comm python bench.py --steps 20 --warmup 3 --no-cpu-baseline
 C2R_BENCH_SHARE_DEVICE=1 run share2 python bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline
+# the 2-, 4- and 8-rank control flow of the RCCL path (c2r_comm_kind 1) on this one device, sums carried by the stand-in of
+# tests/fake_rccl.hip: a rehearsal of `bench.py --gpus N` before a node exists -- the line says STAND-IN and rccl_ranks 0
+for n in 2 4 8; do
+  C2R_BENCH_SHARE_DEVICE=1 C2R_COMM_SHARED_DEVICE_RCCL=1 C2R_RCCL_LIBRARY=$PWD/tests/_fake_rccl.so run standin$n python bench.py --gpus $n --steps 4 --warmup 1 --no-cpu-baseline
+done
 run two_without_second_device python bench.py --gpus 2 --steps 2 --no-cpu-baseline
 run children1 python bench.py --gpus 1 --launcher children --steps 5 --warmup 2 --no-cpu-baseline
 tail -2 "$out/two_without_second_device.err"
