@@ -53,6 +53,9 @@ SYMBOLS = {
     "c2r_set_cooling": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
     "c2r_set_step": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_float, C.c_double, C.c_double, C.c_double,
                                C.c_int, C.c_double, _dp]),
+    "c2r_set_step_scalars": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_float, C.c_double, C.c_double, C.c_double,
+                                       C.c_int, C.c_double, _dp]),
+    "c2r_scale_ndens": (C.c_int, [C.c_void_p, C.c_double]),
     "c2r_set_sources": (C.c_int, [C.c_void_p, C.c_int, _ip, _dp, C.c_double]),
     "c2r_set_sed_tables": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_int]),
     "c2r_set_sources_sed": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_double]),

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1484,6 +1485,12 @@ k_iter_stats_finish(const double *__restrict__ partial, const double *__restrict
   }
 }
 
+// cosmo_evol's ndens(:,:,:) = ndens(:,:,:) / zfactor3 (cosmology.f90:193) on the device copy: one IEEE division per cell,
+// correctly rounded on gfx950 as on the host (c2r_scale_ndens)
+__global__ void __launch_bounds__(BLOCK) k_divide_by(double *__restrict__ a, size_t n, double d) {
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) a[i] = a[i] / d;
+}
+
 } // namespace
 
 // =============================================================================================
@@ -2162,9 +2169,11 @@ static int set_step_one(c2r_ctx *c, const double *ndens, const double dr[3], dou
                             double zred, double H0, double Omega0, int isothermal, double temper_val,
                             const double reccoef[12]) {
   if (!c) return 1;
-  if (!ndens || !dr || !reccoef) return fail(c, "c2r_set_step: null argument");
+  if (!dr || !reccoef) return fail(c, "c2r_set_step: null argument");
+  // ndens == nullptr (c2r_set_step_scalars): the density on the device stays as it is
+  if (!ndens && !c->have_step) return fail(c, "c2r_set_step_scalars: no density on the device yet (c2r_set_step comes first)");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(c->d_ndens, ndens, sizeof(double) * c->g.ncell, hipMemcpyHostToDevice, c->stream));
+  if (ndens) HIPCHK(c, hipMemcpyAsync(c->d_ndens, ndens, sizeof(double) * c->g.ncell, hipMemcpyHostToDevice, c->stream));
   c->isothermal = isothermal ? 1 : 0;
   if (alloc_heating_lists(c)) return 1; // a non-isothermal step: the tiers' lists exist before any pass starts
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3947,6 +3956,25 @@ extern "C" int c2r_set_step(c2r_ctx *c, const double *ndens, const double dr[3],
   return for_replicas(c, [&](c2r_ctx *r) { return set_step_one(r, ndens, dr, vol, clumping, zred, H0, Omega0, isothermal, temper_val, reccoef); });
 }
 
+extern "C" int c2r_set_step_scalars(c2r_ctx *c, const double dr[3], double vol, float clumping, double zred, double H0, double Omega0, int isothermal, double temper_val, const double reccoef[12]) {
+  if (set_step_one(c, nullptr, dr, vol, clumping, zred, H0, Omega0, isothermal, temper_val, reccoef)) return 1;
+  return for_replicas(c, [&](c2r_ctx *r) { return set_step_one(r, nullptr, dr, vol, clumping, zred, H0, Omega0, isothermal, temper_val, reccoef); });
+}
+static int scale_ndens_one(c2r_ctx *c, double divisor) {
+  if (!c->have_step) return fail(c, "c2r_scale_ndens: no density on the device yet");
+  if (!(divisor > 0.0) || !std::isfinite(divisor)) return fail(c, "c2r_scale_ndens: divisor %g", divisor);
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nblk = (int)std::min<size_t>(65535, (c->g.ncell + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL(k_divide_by, dim3(nblk), dim3(BLOCK), 0, c->stream, c->d_ndens, c->g.ncell, divisor);
+  HIPCHK(c, hipGetLastError());
+  c->packed_valid = c->transposed_valid = false; // the products neufrac * ndens of the sweep are stale
+  return 0;
+}
+extern "C" int c2r_scale_ndens(c2r_ctx *c, double divisor) {
+  if (!c) return 1;
+  if (scale_ndens_one(c, divisor)) return 1;
+  return for_replicas(c, [&](c2r_ctx *r) { return scale_ndens_one(r, divisor); });
+}
 extern "C" int c2r_set_sources(c2r_ctx *c, int nsrc, const int *srcpos, const double *normflux, double s_star) {
   if (int e_ = set_sources_one(c, nsrc, srcpos, normflux, s_star)) return e_;
   return for_replicas(c, [&](c2r_ctx *r) { return set_sources_one(r, nsrc, srcpos, normflux, s_star); });

@@ -308,6 +308,18 @@ class HipEngine:
                                        None if lls is None else lls.ctypes.data_as(fp)))
         self._chk(self.lib.c2r_set_clumping_grid(self.h, None if cg is None else cg.ctypes.data_as(fp)))
 
+    def set_step_scalars(self, mat: Material, grid: GridProps, cosmo: Cosmology):
+        """c2r_set_step without the density: what is on the device stays (see scale_ndens)."""
+        dr = (C.c_double * 3)(*[float(x) for x in grid.dr])
+        rc = _f64(mat.reccoef).reshape(-1)
+        self.isothermal = bool(mat.isothermal)
+        self._chk(self.lib.c2r_set_step_scalars(self.h, dr, float(grid.vol), float(mat.clumping), float(cosmo.zred), float(cosmo.H0),
+                                                float(cosmo.Omega0), int(bool(mat.isothermal)), float(mat.temper_val), _dp(rc)))
+
+    def scale_ndens(self, divisor):
+        """cosmo_evol's ndens = ndens / zfactor3 on the device copy (cosmology.f90:193)."""
+        self._chk(self.lib.c2r_scale_ndens(self.h, float(divisor)))
+
     def set_sources(self, src: SourceProps):
         pos = np.ascontiguousarray(src.srcpos, dtype=np.int32).reshape(-1)
         nf = _f64(src.NormFlux).reshape(-1)

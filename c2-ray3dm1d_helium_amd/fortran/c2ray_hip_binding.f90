@@ -91,6 +91,25 @@ module c2ray_hip
        real(c_double), intent(in) :: reccoef(12)
      end function c2r_set_step
 
+     integer(c_int) function c2r_set_step_scalars(ctx, dr, vol, clumping, zred, H0, Omega0, &
+          isothermal, temper_val, reccoef) bind(C, name="c2r_set_step_scalars")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: dr(3)
+       real(c_double), value :: vol
+       real(c_float), value :: clumping
+       real(c_double), value :: zred, H0, Omega0
+       integer(c_int), value :: isothermal
+       real(c_double), value :: temper_val
+       real(c_double), intent(in) :: reccoef(12)
+     end function c2r_set_step_scalars
+
+     integer(c_int) function c2r_scale_ndens(ctx, divisor) bind(C, name="c2r_scale_ndens")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), value :: divisor
+     end function c2r_scale_ndens
+
      integer(c_int) function c2r_set_sources(ctx, nsrc, srcpos, normflux, s_star) &
           bind(C, name="c2r_set_sources")
        import :: c_int, c_ptr, c_double

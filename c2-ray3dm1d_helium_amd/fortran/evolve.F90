@@ -87,6 +87,20 @@ module evolve
   !> evolve_data's phiheat still holds the zeros it was allocated with (see download_rates)
   logical :: phiheat_host_is_zero = .true.
   integer :: allreduce_slabs = 4
+  !> C2RAY_HIP_KEEP_STATE (opt-in, INTEGRATION.md): what the device already holds is not sent again, what no routine of
+  !! the reference reads on the host is not brought back.  1: xh, xhe, temperature_grid are uploaded only when a sample of
+  !! the host arrays differs from what this module downloaded at the end of the previous call; ndens only when it is neither
+  !! unchanged nor the previous array divided by cosmo_evol's zfactor**3 (the division is then made on the device copy);
+  !! phihe_grid stays on the device (only the iteration dump reads it, and fetches it itself).  2: phih_grid and phiheat
+  !! stay there as well -- for runs without output stream 3, their only reader (output.F90:311-379).
+  integer :: keep_state = 0
+  integer,parameter :: nfp = 8192 !< samples of a fingerprint
+  logical :: fp_valid = .false. !< the fingerprints below describe host arrays that equal the device's
+  integer(kind=8) :: fp_xh(nfp), fp_xhe(nfp), fp_ndens(nfp)
+  integer(kind=4) :: fp_temp(nfp)
+  real(kind=dp) :: fp_ndens_value(nfp) !< the sampled densities themselves (for the zfactor**3 test)
+  real(kind=dp) :: prev_zred = 0.0_dp, prev_dr(3) = 0.0_dp, prev_vol = 0.0_dp
+  logical :: prev_isothermal = .true.
   !> what c2r_iteration reported about the iteration in flight, for global_pass to log
   type(c2r_iteration_report) :: report
   logical :: report_valid = .false.
@@ -134,8 +148,7 @@ contains
     if (isothermal) iso = 1
     reccoef = (/ arech0, brech0, areche0, breche0, oreche0, areche1, breche1, treche1, &
          colli_HI, colli_HeI, colli_HeII, v /)
-    call check (c2r_set_step (hip_ctx, ndens, dr, vol, real(clumping,c_float), zred, H0, Omega0, &
-         iso, temper_val, reccoef), "c2r_set_step")
+    call send_step (iso, reccoef)
     call pass_subgrid_fields ()
     if (NumSrc > 0) then
        call check (c2r_set_sources (hip_ctx, int(NumSrc,c_int), srcpos, NormFlux(1:NumSrc), S_star), &
@@ -154,7 +167,11 @@ contains
 #endif
     tptr = c_null_ptr
     if (.not.isothermal) tptr = c_loc_real4 (temperature_grid)
-    call check (c2r_upload_state (hip_ctx, xh, xhe, tptr), "c2r_upload_state")
+    if (state_is_on_device (restart)) then
+       if (rank == 0) write(logf,*) "evolve3D: xh, xhe, temperature_grid kept on the device (C2RAY_HIP_KEEP_STATE)"
+    else
+       call check (c2r_upload_state (hip_ctx, xh, xhe, tptr), "c2r_upload_state")
+    endif
 
     ! Initial state (for photon statistics): state_before (photonstatistics.f90:117-144)
     call check (c2r_state_sums (hip_ctx, 0_c_int, n_before), "c2r_state_sums")
@@ -238,6 +255,7 @@ contains
     ! --- results back to the modules that own them
     call check (c2r_download_state (hip_ctx, xh, xhe, tptr), "c2r_download_state")
     call download_rates ()
+    if (keep_state > 0) call remember_host_state ()
 
     ! Calculate photon statistics: calculate_photon_statistics (dt,xh,xh_av,xhe,xhe_av)
     call check (c2r_state_sums (hip_ctx, 0_c_int, n_after), "c2r_state_sums")
@@ -253,6 +271,141 @@ contains
          real(callclock2-loopclock2,dp)/real(countspersec,dp), " s"
 
   end subroutine evolve3D
+
+  ! ===========================================================================
+
+  !> c2r_set_step: the scalars of the step and material's ndens -- which, with C2RAY_HIP_KEEP_STATE, is sent only when the
+  !! device's copy cannot be brought to the same bits otherwise
+  subroutine send_step (iso, reccoef)
+
+    integer(c_int),intent(in) :: iso
+    real(kind=dp),intent(in) :: reccoef(12)
+
+    integer(kind=8) :: fp_now(nfp)
+    real(kind=dp) :: now_value(nfp), zfactor, zfactor3
+    integer(kind=8) :: n
+    logical :: same, scaled
+    integer :: k
+
+    n = int(mesh(1),8)*int(mesh(2),8)*int(mesh(3),8)
+    same = .false.
+    scaled = .false.
+    if (keep_state > 0 .and. fp_valid) then
+       call sample8 (ndens, n, fp_now, now_value)
+       same = all(fp_now == fp_ndens)
+       if (.not.same .and. prev_zred > 0.0_dp) then
+          ! redshift_evol's zfactor (cosmology.f90:149, a private variable) from the same operands, cosmo_evol's
+          ! zfactor3 (:177), and the three things it did with them (:184-193) -- all to the bit, or the array is sent
+          zfactor=(1.0+prev_zred)/(1.+zred)
+          zfactor3=zfactor*zfactor*zfactor
+          scaled = all(transfer(prev_dr(:)*zfactor,1_8,3) == transfer(dr(:),1_8,3)) .and. &
+               transfer(prev_vol*zfactor3,1_8) == transfer(vol,1_8)
+          if (scaled) then
+             do k=1,nfp
+                if (transfer(fp_ndens_value(k)/zfactor3,1_8) /= fp_now(k)) scaled = .false.
+             enddo
+          endif
+       endif
+    endif
+    if (same .or. scaled) then
+       if (scaled) call check (c2r_scale_ndens (hip_ctx, zfactor3), "c2r_scale_ndens")
+       call check (c2r_set_step_scalars (hip_ctx, dr, vol, real(clumping,c_float), zred, H0, Omega0, &
+            iso, temper_val, reccoef), "c2r_set_step_scalars")
+       if (rank == 0 .and. scaled) write(logf,*) "evolve3D: ndens rescaled on the device (C2RAY_HIP_KEEP_STATE)"
+       if (rank == 0 .and. same) write(logf,*) "evolve3D: ndens kept on the device (C2RAY_HIP_KEEP_STATE)"
+    else
+       call check (c2r_set_step (hip_ctx, ndens, dr, vol, real(clumping,c_float), zred, H0, Omega0, &
+            iso, temper_val, reccoef), "c2r_set_step")
+    endif
+
+  end subroutine send_step
+
+  ! ===========================================================================
+
+  !> Is what the device holds since the end of the previous evolve3D call still what material's arrays hold?
+  function state_is_on_device (restart) result(kept)
+
+    integer,intent(in) :: restart
+    logical :: kept
+
+    integer(kind=8) :: fp8(nfp)
+    integer(kind=4) :: fp4(nfp)
+    real(kind=dp) :: values(nfp)
+    integer(kind=8) :: n
+
+    kept = .false.
+    if (keep_state == 0 .or. .not.fp_valid .or. restart /= 0) return
+    if (isothermal .neqv. prev_isothermal) return
+    n = int(mesh(1),8)*int(mesh(2),8)*int(mesh(3),8)
+    call sample8 (xh, 2*n, fp8, values)
+    if (any(fp8 /= fp_xh)) return
+    call sample8 (xhe, 3*n, fp8, values)
+    if (any(fp8 /= fp_xhe)) return
+    if (.not.isothermal) then
+       call sample4 (temperature_grid, 3*n, fp4)
+       if (any(fp4 /= fp_temp)) return
+    endif
+    kept = .true.
+
+  end function state_is_on_device
+
+  ! ===========================================================================
+
+  !> after the results of a call have reached the host: what they look like, and the scalars cosmo_evol will change
+  subroutine remember_host_state ()
+
+    integer(kind=8) :: n
+    real(kind=dp) :: values(nfp)
+
+    n = int(mesh(1),8)*int(mesh(2),8)*int(mesh(3),8)
+    call sample8 (xh, 2*n, fp_xh, values)
+    call sample8 (xhe, 3*n, fp_xhe, values)
+    if (.not.isothermal) call sample4 (temperature_grid, 3*n, fp_temp)
+    call sample8 (ndens, n, fp_ndens, fp_ndens_value)
+    prev_zred = zred
+    prev_dr(:) = dr(:)
+    prev_vol = vol
+    prev_isothermal = isothermal
+    fp_valid = .true.
+
+  end subroutine remember_host_state
+
+  ! ===========================================================================
+
+  !> bit patterns of nfp elements of a real(dp) array taken as flat: evenly spread, the last one included
+  subroutine sample8 (a, n, bits, values)
+
+    real(kind=dp),intent(in) :: a(*)
+    integer(kind=8),intent(in) :: n
+    integer(kind=8),intent(out) :: bits(nfp)
+    real(kind=dp),intent(out) :: values(nfp)
+
+    integer :: k
+    integer(kind=8) :: idx
+
+    do k=1,nfp
+       idx = 1_8 + ((n-1_8)*int(k-1,8))/int(nfp-1,8)
+       values(k) = a(idx)
+       bits(k) = transfer(a(idx),1_8)
+    enddo
+
+  end subroutine sample8
+
+  subroutine sample4 (a, n, bits)
+
+    real(kind=4),intent(in) :: a(*)
+    integer(kind=8),intent(in) :: n
+    integer(kind=4),intent(out) :: bits(nfp)
+
+    integer :: k
+    integer(kind=8) :: idx
+
+    do k=1,nfp
+       idx = 1_8 + ((n-1_8)*int(k-1,8))/int(nfp-1,8)
+       bits(k) = transfer(a(idx),1_4)
+    enddo
+
+  end subroutine sample4
 
   ! ===========================================================================
 
@@ -507,6 +660,12 @@ contains
     endif
     ! with the loop's clock also the kernels of every iteration (HIP events on the library's streams)
     if (loop_timing) call check (c2r_enable_timing (hip_ctx, 1_c_int), "c2r_enable_timing")
+    call get_environment_variable ("C2RAY_HIP_KEEP_STATE", text, length, status)
+    if (status == 0 .and. length > 0) then
+       read(text(1:length),*,iostat=status) n
+       if (status == 0 .and. n >= 0 .and. n <= 2) keep_state = n
+    endif
+    if (rank == 0 .and. keep_state > 0) write(logf,*) "evolve3D: C2RAY_HIP_KEEP_STATE = ", keep_state
     call get_environment_variable ("C2R_ALLREDUCE_SLABS", text, length, status)
     if (status == 0 .and. length > 0) then
        read(text(1:length),*,iostat=status) n
@@ -528,9 +687,11 @@ contains
   ! ===========================================================================
 
   !> phih_grid, phihe_grid, phiheat, photon_loss_all, sum_nbox to their host mirrors
-  subroutine download_rates ()
+  subroutine download_rates (everything)
 
+    logical,intent(in),optional :: everything !< whatever C2RAY_HIP_KEEP_STATE says (the iteration dump holds all of them)
     integer(c_int) :: nbox, which
+    logical :: all_of_them
 #ifdef C2RAY_REFERENCE_DO_SOURCE
     real(kind=dp) :: tail(NumFreqBnd)
 #endif
@@ -540,6 +701,12 @@ contains
     which = 7
     if (isothermal .and. phiheat_host_is_zero) which = 3
     if (.not.isothermal) phiheat_host_is_zero = .false.
+    ! C2RAY_HIP_KEEP_STATE: phihe_grid has no reader on the host but the iteration dump (which fetches it itself,
+    ! write_iteration_dump); with level 2 neither have phih_grid and phiheat (output stream 3 is off, says the host)
+    all_of_them = .false.
+    if (present(everything)) all_of_them = everything
+    if (keep_state >= 1 .and. .not.all_of_them) which = iand(which, 5)
+    if (keep_state >= 2 .and. .not.all_of_them) which = 0
 #ifdef C2RAY_REFERENCE_DO_SOURCE
     call check (c2r_download_rates_sel (hip_ctx, which, phih_grid, phihe_grid, phiheat, tail, nbox), "c2r_download_rates")
 #else
@@ -563,7 +730,7 @@ contains
 
     write(timefile,"(A,F8.1)") "Time before writing iterdump: ", timestamp_wallclock ()
 
-    call download_rates ()
+    call download_rates (everything=.true.)
     call check (c2r_download_iter_state (hip_ctx, xh_av, xhe_av, xh_intermed, xhe_intermed), &
          "c2r_download_iter_state")
     if (.not.isothermal) then

@@ -60,6 +60,15 @@ int c2r_set_cooling(c2r_ctx *ctx, const double *cool5x801, double mintemp, doubl
 int c2r_set_step(c2r_ctx *ctx, const double *ndens, const double dr[3], double vol, float clumping,
                  double zred, double H0, double Omega0, int isothermal, double temper_val,
                  const double reccoef[12]);
+/* The same without the density: material:ndens on the device stays as the last c2r_set_step (or c2r_scale_ndens) left it.
+ * For hosts that know ndens has not changed since (a run without cosmological expansion), or has only been rescaled: */
+int c2r_set_step_scalars(c2r_ctx *ctx, const double dr[3], double vol, float clumping, double zred, double H0, double Omega0,
+                         int isothermal, double temper_val, const double reccoef[12]);
+/* cosmo_evol's  ndens(:,:,:) = ndens(:,:,:) / zfactor3  (cosmology.f90:193) applied to the device copy: one correctly
+ * rounded IEEE division per cell, the same bits as the host's.  The Fortran drop-in uses the two calls when
+ * C2RAY_HIP_KEEP_STATE is set and a sample of the host array confirms that this is all that happened to it. */
+int c2r_scale_ndens(c2r_ctx *ctx, double divisor);
+
 
 /* Table construction on the device: spec_integration (radiation_tables.f90:172-422) for one SED from what
  * spectrum_parms, setup_scalingfactors (radiation_sizes.f90:62-688), romberg_initialisation(NumFreq)

@@ -52,7 +52,7 @@ def ref_binary(mesh: int, which: str = "tap", omp: bool = False, pl: bool = Fals
 
 def run_reference(mesh: int, sources, *, T0=1e4, isothermal=True, steps_per_slice=1,
                   outputs_per_slice=1, which="tap", omp=False, name=None, threads=1,
-                  timeout=3600, keep=True, pl=False, lls=False):
+                  timeout=3600, keep=True, pl=False, lls=False, streams="0 1 1 0 0"):
     """Run the reference; returns the run directory (results in <run>/results).
     sources: (i, j, k, S_BB) or, for the -DPL -DQUASARS build (pl=True), (i, j, k, S_BB, S_PL, S_QPL)."""
     exe = ref_binary(mesh, which, omp, pl, lls)
@@ -69,7 +69,7 @@ def run_reference(mesh: int, sources, *, T0=1e4, isothermal=True, steps_per_slic
             i, j, k = src[:3]
             f.write(f"{i} {j} {k} " + " ".join(f"{x:.6e}" for x in src[3:]) + "\n")
     with open(run / "input", "w") as f:
-        f.write("0 1 1 0 0\n")
+        f.write(streams + "\n")                          # output streams 1..5 (output.F90:90)
         f.write(f"{T0:g}\n")
         f.write("y\n" if isothermal else "n\n")
         f.write("n\nn\n1\n")

@@ -61,6 +61,13 @@ def _reference_snapshot(golden_name, run_reference):
     # sweeping one of the two sources, the in-process sum over the replicas, replicated chemistry.  Two sources
     # over two ranks add up as (0 + s1) + s2 either way: still byte-identical files
     (False, "ngpu2", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
+    # C2RAY_HIP_KEEP_STATE=1 (opt-in): from the second evolve3D call on xh, xhe, temperature_grid stay on the device when a
+    # sample of the host arrays still shows what the previous call downloaded, ndens is divided by cosmo_evol's zfactor**3 on
+    # the device when that is all that happened to it (two time steps per slice: the step inside a slice), sent otherwise
+    # (the first step of a slice: two cosmo_evol calls lie in between), and phihe_grid is not brought to the host
+    (False, "keepstate", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
+    # ... =2, for runs without output stream 3 (the only reader of phih_grid / phiheat on the host): no rate grid comes back
+    (True, "keepstate2", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
     # the -DPL -DQUASARS build (the flags of the reference's production targets, Makefile:185-186,207-208)
     (False, True, [(8, 8, 8, 1e55, 3e54, 0.0), (2, 15, 4, 0.0, 2e54, 4e54), (16, 1, 9, 2e54, 0.0, 1e54)]),
 ])
@@ -82,21 +89,27 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     stepwise = pl == "stepwise"
     if stepwise:
         monkeypatch.setenv("C2RAY_HIP_STEPWISE", "1")
+    keep = {"keepstate": 1, "keepstate2": 2}.get(pl, 0)
+    if keep:
+        monkeypatch.setenv("C2RAY_HIP_KEEP_STATE", str(keep))
+    steps = 2 if keep else 1
+    streams = "0 1 0 0 0" if keep == 2 else "0 1 1 0 0"
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
     which_hip = "hip_dogrid" if dogrid else ("hip_bycell" if bycell else ("hip_bypoint" if bypoint else "hip"))
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "") + (f"_keepstate{keep}" if keep else "")
     import make_golden_dropin
     if pl:
         assert sources == make_golden_dropin.PL_SOURCES and not iso     # what the fixture was made from
     s1 = _reference_snapshot("dropin_ref_heat_pl.json" if pl else None,
-                             lambda: refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which="test",
-                                                          name=f"dropin_ref_{tag}", pl=pl, lls=lls))
-    r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=1, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls)
+                             lambda: refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=steps, which="test",
+                                                          name=f"dropin_ref_{tag}", pl=pl, lls=lls, streams=streams))
+    r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=steps, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls,
+                              streams=streams)
     s2 = json.loads(json.dumps(make_golden_dropin.snapshot(r2)))
-    assert len(s1["sha256"]) >= 15, sorted(s1["sha256"])
+    assert len(s1["sha256"]) >= (9 if keep == 2 else 15), sorted(s1["sha256"])
     # every output file byte for byte (SHA-256 of the reference's file against the drop-in's)
     assert sorted(s1["sha256"]) == sorted(s2["sha256"])
     for f in s1["sha256"]:
@@ -104,6 +117,11 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     # same iteration history in the log
     assert s1["log_calls"] == s2["log_calls"]
     log2 = (r2 / "results" / "C2Ray.log").read_text(errors="replace")
+    if keep:
+        # 8 calls: state kept from the second on; ndens rescaled on the device inside a slice (calls 2, 4, 6, 8), sent at
+        # the start of a slice, where cosmo_evol ran twice since the call before
+        assert log2.count("xh, xhe, temperature_grid kept on the device") == 7, log2.count("kept on the device")
+        assert log2.count("ndens rescaled on the device") == 4
     if devtables:
         assert "tables built on the device for SED  0" in log2
     if comm1:

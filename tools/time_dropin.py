@@ -30,6 +30,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mesh", type=int, default=256)
     ap.add_argument("--stepwise", action="store_true", help="C2RAY_HIP_STEPWISE=1: the reference's call-by-call loop")
+    ap.add_argument("--keep-state", type=int, default=0, help="C2RAY_HIP_KEEP_STATE: 1 keeps xh / xhe / ndens on the device between calls when "
+                    "a sample of the host arrays allows it and leaves phihe_grid there; 2 leaves every rate grid there (no output stream 3)")
+    ap.add_argument("--no-bench", action="store_true", help="skip the bench.py run on the same iterations")
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "dropin_timing.json"))
     a = ap.parse_args()
     import refrun
@@ -55,6 +58,8 @@ def main():
     env["C2RAY_HIP_TIMING"] = "1"
     if a.stepwise:
         env["C2RAY_HIP_STEPWISE"] = "1"
+    if a.keep_state:
+        env["C2RAY_HIP_KEEP_STATE"] = str(a.keep_state)
     t0 = time.perf_counter()
     with open(run / "stdout.txt", "w") as so:
         subprocess.run([str(exe), "input"], cwd=run, env=env, stdout=so, stderr=subprocess.STDOUT, timeout=1500, check=True)
@@ -87,8 +92,16 @@ def main():
         raise SystemExit("no 'evolve3D loop' line in Timings.log")
     sys.path.insert(0, str(ROOT))
     import bench
-    out = {"source_sha16": bench.kernel_source_sha16(), "binary": str(exe.relative_to(ROOT)), "mode": "stepwise" if a.stepwise else "c2r_iteration", "driver_wall_s": wall,
+    out = {"source_sha16": bench.kernel_source_sha16(), "binary": str(exe.relative_to(ROOT)), "mode": "stepwise" if a.stepwise else "c2r_iteration", "keep_state": a.keep_state, "driver_wall_s": wall,
            "evolve3D_calls": calls, "iterations": calls[0]["iterations"], "ms_per_iteration": calls[0]["ms_per_iteration"]}
+    log = (run / "results" / "C2Ray.log").read_text(errors="replace")
+    out["calls_with_state_kept"] = log.count("xh, xhe, temperature_grid kept on the device")
+    out["calls_with_ndens_kept_or_rescaled"] = log.count("ndens kept on the device") + log.count("ndens rescaled on the device")
+    if a.no_bench:
+        Path(a.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(a.out).write_text(json.dumps(out, indent=1))
+        print(json.dumps(out, indent=1))
+        return
     # the Python host on the same iterations of the same first time step
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--neutral-start", "--warmup", "0", "--steps", str(calls[0]["iterations"]),
                         "--no-cpu-baseline", "--mesh", str(n)], capture_output=True, text=True, timeout=900)
