@@ -53,6 +53,7 @@ SYMBOLS = {
     "c2r_set_cooling": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double]),
     "c2r_set_step": (C.c_int, [C.c_void_p, _dp, _dp, C.c_double, C.c_float, C.c_double, C.c_double, C.c_double,
                                C.c_int, C.c_double, _dp]),
+    "c2r_arena_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "c2r_set_step_scalars": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_float, C.c_double, C.c_double, C.c_double,
                                        C.c_int, C.c_double, _dp]),
     "c2r_scale_ndens": (C.c_int, [C.c_void_p, C.c_double]),

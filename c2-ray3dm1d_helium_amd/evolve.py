@@ -316,6 +316,12 @@ class HipEngine:
         self._chk(self.lib.c2r_set_step_scalars(self.h, dr, float(grid.vol), float(mat.clumping), float(cosmo.zred), float(cosmo.H0),
                                                 float(cosmo.Omega0), int(bool(mat.isothermal)), float(mat.temper_val), _dp(rc)))
 
+    def arena_stats(self):
+        """c2r_arena_stats as a dict (column scratch: segments allocated, of them inside a pass, ...)."""
+        out = (C.c_longlong * 6)()
+        self._chk(self.lib.c2r_arena_stats(self.h, out))
+        return dict(zip(("segments", "segments_in_pass", "doubles_allocated", "block_moves", "batch_restarts", "doubles_held"), out))
+
     def scale_ndens(self, divisor):
         """cosmo_evol's ndens = ndens / zfactor3 on the device copy (cosmology.f90:193)."""
         self._chk(self.lib.c2r_scale_ndens(self.h, float(divisor)))

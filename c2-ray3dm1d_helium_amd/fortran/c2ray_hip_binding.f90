@@ -104,6 +104,12 @@ module c2ray_hip
        real(c_double), intent(in) :: reccoef(12)
      end function c2r_set_step_scalars
 
+     integer(c_int) function c2r_arena_stats(ctx, out) bind(C, name="c2r_arena_stats")
+       import :: c_int, c_ptr, c_long_long
+       type(c_ptr), value :: ctx
+       integer(c_long_long), intent(out) :: out(6)
+     end function c2r_arena_stats
+
      integer(c_int) function c2r_scale_ndens(ctx, divisor) bind(C, name="c2r_scale_ndens")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx

@@ -350,6 +350,12 @@ typedef struct {
   long long cells_swept; /* cell x source pairs actually traced by the last c2r_pass_sources */
 } c2r_timing;
 int c2r_get_timing(c2r_ctx *ctx, c2r_timing *out);
+/* The column scratch (the reference's coldensh_out / coldenshe_out per source in flight, evolve_source.F90:94-95) since the
+ * context was made: out[0] device segments allocated, out[1] of them INSIDE a pass (the others by c2r_begin_step, which sizes
+ * the scratch of a time step from the sub-box counts the step before ended with), out[2] doubles allocated in all, out[3]
+ * column blocks moved to deeper ones in the middle of a sweep, out[4] batches that started over for lack of room,
+ * out[5] doubles held now. */
+int c2r_arena_stats(const c2r_ctx *ctx, long long out[6]);
 /* the same for device `idev` (0 .. c2r_num_devices-1) of a context made by c2r_create_multi */
 int c2r_get_timing_device(c2r_ctx *ctx, int idev, c2r_timing *out);
 int c2r_enable_timing(c2r_ctx *ctx, int on);
