@@ -1567,6 +1567,7 @@ struct c2r_ctx {
   size_t seg_cur[2] = {0, 0}, seg_used[2] = {0, 0}; // bump allocation within a batch
   size_t arena_total = 0;                          // doubles in all segments
   std::vector<int> prev_nbox;      // per source: sub-boxes of the last pass (0: unknown), sizes the next block
+  std::vector<int> prev_grow;      // per source: by how many sub-boxes its box grew from the pass before last to the last one
   int last_first = 0, last_stride = 0; // the share of the sources the last pass swept: first, first + stride, ... (arena_prepare plans the next step's scratch for it)
   bool in_pass = false;            // pass_list is running (arena statistics: allocations that land inside an iteration)
   long long arena_stats[5] = {0, 0, 0, 0, 0}; // segments allocated, of them inside a pass, doubles allocated, block moves, batch restarts
@@ -2490,6 +2491,17 @@ static StepScalars scalars(c2r_ctx *c) {
 // made now, it does not land inside an outer iteration (round-4 VERDICT: 0.3-0.8 s of such allocations, and a batch that
 // started over, inside iterations 6 and 7 of profiles/r04_config4_call.json).  What cannot be known -- a first time step from a
 // neutral start, a source that brightens -- still grows inside a pass, as before.
+// Shells a source's column block is made for: the sub-boxes it needed in the last pass plus one round -- plus as many as its
+// box grew by between the last two passes when it is growing faster than that (while the ionisation fronts of a first
+// time step break out, boxes jump several rounds per iteration: a block sized for one more round then moved to one twice
+// as deep in the middle of the sweep, its old place lay idle until the batch was over, and a batch that ran out of room
+// that way started over); four rounds when nothing is known; never more than the mesh.
+static int predicted_shells(const c2r_ctx *c, int ns) {
+  const int prev = c->prev_nbox[(size_t)ns - 1];
+  const int grow = c->prev_grow.size() == c->prev_nbox.size() ? c->prev_grow[(size_t)ns - 1] : 0;
+  return std::min(c->g.smax, SUBBOXSIZE * (prev > 0 ? prev + std::max(1, 2 * grow) : 4));
+}
+
 static int arena_prepare(c2r_ctx *c) {
   if (c->last_stride < 1 || c->prev_nbox.size() != (size_t)c->nsrc) return 0;
   std::vector<int> mine; // this context's share, as the last pass had it (do_grid_static: first = 1 + rank, stride = ranks)
@@ -2500,8 +2512,7 @@ static int arena_prepare(c2r_ctx *c) {
   for (size_t b0 = 0; b0 < mine.size(); b0 += (size_t)limit, bi++) {
     size_t sum = 0, spare = 0;
     for (size_t b = b0; b < std::min(mine.size(), b0 + (size_t)limit); b++) {
-      const int prev = c->prev_nbox[(size_t)mine[b] - 1];
-      const int cap = std::min(c->g.smax, SUBBOXSIZE * (prev > 0 ? prev + 1 : 4)); // pass_list's predicted_cap
+      const int cap = predicted_shells(c, mine[b]); // pass_list's predicted_cap
       sum += block_doubles(cap);
       // ... and room for ONE source of the batch to outgrow that (its block then moves to one twice as deep)
       if (cap < c->g.smax) spare = std::max(spare, block_doubles(std::min(c->g.smax, 2 * cap)));
@@ -2585,6 +2596,7 @@ static int set_batch_one(c2r_ctx *c, int nbatch) {
 
 // host-side sub-box bookkeeping of one source (do_source, evolve_source.F90:96-144, 233-236)
 struct SrcRun {
+  int known_before = 0;   // prev_nbox of the source when the batch was first put together
   int ns;                 // 1-based source number
   int nbox = 0;
   double total_flux = 0, loss = 0;
@@ -2840,10 +2852,8 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
   }
   // column blocks: what a source needed in the last pass plus one round, or four rounds when nothing is known;
   // never less than one round, never more than the mesh
-  auto predicted_cap = [&](int ns) {
-    const int prev = c->prev_nbox[(size_t)ns - 1];
-    return std::min(g.smax, SUBBOXSIZE * (prev > 0 ? prev + 1 : 4));
-  };
+  if (c->prev_grow.size() != (size_t)c->nsrc) c->prev_grow.assign((size_t)c->nsrc, 0);
+  auto predicted_cap = [&](int ns) { return predicted_shells(c, ns); };
   int bi = 0;
   int batch_limit = std::min(c->batch, BATCH_MAX);
   for (size_t b0 = 0; b0 < mine.size(); bi++) {
@@ -2857,8 +2867,12 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       resolve_tails(c, set); // h_final[set] is about to be written again
     }
     std::vector<SrcRun> run;
+    std::vector<int> known0((size_t)nb); // what the last pass knew about the batch's sources (a batch that starts over raises prev_nbox)
+    for (int b = 0; b < nb; b++) known0[(size_t)b] = c->prev_nbox[(size_t)mine[b0 + b] - 1];
+    int restarts = 0;
   restart_batch:
     run.assign((size_t)nb, SrcRun());
+    for (int b = 0; b < nb; b++) run[(size_t)b].known_before = known0[(size_t)b];
     {
       // Blocks of this batch.  Segments are kept from batch to batch and pass to pass (allocation is slow), so what
       // the set holds may be cut for other block sizes than this batch needs (many small segments of a pass with
@@ -3041,7 +3055,9 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           }
           if (nb == 1) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
           if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d: no room to grow in round %d, batch of %d starts over\n", set, round, nb);
-          nb = (nb + 1) / 2;
+          // the first time with the same sources: blocks made for what is known now need no moves, and what a move leaves
+          // behind is most of what filled the set; a batch that runs out of room again is halved
+          if (restarts++ > 0) nb = (nb + 1) / 2;
           c->arena_stats[4]++;
           goto restart_batch;
         }
@@ -3153,7 +3169,12 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
         any_final = true;
         S.loss_lo = run[b].nbox > 1 ? box_smax(round_box(reach, run[b].nbox - 1)) + 1 : 0;
       }
-      c->prev_nbox[(size_t)run[b].ns - 1] = run[b].nbox;
+      {
+        int &pn = c->prev_nbox[(size_t)run[b].ns - 1];
+        // (first_try_nbox: what was known before this batch -- a batch that started over has raised prev_nbox meanwhile)
+        c->prev_grow[(size_t)run[b].ns - 1] = run[b].known_before > 0 ? std::max(0, run[b].nbox - run[b].known_before) : 0;
+        pn = run[b].nbox;
+      }
     }
     if (c->timing) { // the sweep's span: from the first shell launch to the last, record uploads on either side left out
       if (!sweep_started) HIPCHK(c, hipEventRecord(e_s0, c->stream));
