@@ -35,6 +35,44 @@
 #endif
 
 #define C2R_F(x) ((double)(x##f))
+#define C2R_FX(x) C2R_F(x) // the same for a literal that arrives through a macro (expanded before the suffix is pasted)
+
+// The numerical parameters of the reference's c2ray_parameters.f90 and abundances.f90 that are compiled into the device
+// code.  A host built with another c2ray_parameters*.f90 rebuilds the library with the same values:
+//     _build.build(params={"subboxsize": 5, "convergence_fraction": "1.0e-4"})    or   C2R_PARAMS="subboxsize=5,..."
+// (-DC2R_PARAM_<NAME>=<the Fortran literal without kind suffix>; REAL(4) parameters are rounded to single first, as the
+// reference's bare literals are).  c2r_get_constants reports what a library was built with, and the Fortran shim refuses
+// a library whose values differ from its modules' (evolve_data.F90: check_compiled_constants).
+#ifndef C2R_PARAM_SUBBOXSIZE
+#define C2R_PARAM_SUBBOXSIZE 10                  /* integer, c2ray_parameters.f90:51 */
+#endif
+#ifndef C2R_PARAM_MAX_SUBBOX
+#define C2R_PARAM_MAX_SUBBOX 1150                /* integer, :56 */
+#endif
+#ifndef C2R_PARAM_EPSILON
+#define C2R_PARAM_EPSILON 1.0e-20                /* real(dp), :32 */
+#endif
+#ifndef C2R_PARAM_CONVERGENCE_FRACTION
+#define C2R_PARAM_CONVERGENCE_FRACTION 2.5e-4    /* real(4) literal, :26 */
+#endif
+#ifndef C2R_PARAM_MINIMUM_FRACTIONAL_CHANGE
+#define C2R_PARAM_MINIMUM_FRACTIONAL_CHANGE 1.0e-2 /* :36 */
+#endif
+#ifndef C2R_PARAM_MINIMUM_FRACTION_OF_ATOMS
+#define C2R_PARAM_MINIMUM_FRACTION_OF_ATOMS 1.0e-8 /* :44 */
+#endif
+#ifndef C2R_PARAM_MINITEMP
+#define C2R_PARAM_MINITEMP 1.0                   /* :87 */
+#endif
+#ifndef C2R_PARAM_RELATIVE_DENERGY
+#define C2R_PARAM_RELATIVE_DENERGY 0.1           /* :89 */
+#endif
+#ifndef C2R_PARAM_ABU_HE
+#define C2R_PARAM_ABU_HE 0.074                   /* abundances.f90:23 */
+#endif
+#ifndef C2R_PARAM_ABU_C
+#define C2R_PARAM_ABU_C 7.1e-7                   /* abundances.f90:26 */
+#endif
 
 #if !defined(C2R_USE_PLATFORM_LIBM)
 #define C2R_LOGTAB_DEFAULT ::c2r::gm::log_table()
@@ -50,13 +88,13 @@ constexpr int NTAU = 2000;   // radiation_sizes.f90:18
 constexpr int NTAUP = 2002;  // device column pitch: rows 0..2000 plus one duplicate of row 2000
 constexpr int NCOOL = 801;   // cooling_h.f90:25
 constexpr int NB1 = 1, NB2 = 26, NB3 = 20;
-constexpr int SUBBOXSIZE = 10;   // c2ray_parameters.f90:51
-constexpr int MAX_SUBBOX = 1150; // c2ray_parameters.f90:56
+constexpr int SUBBOXSIZE = C2R_PARAM_SUBBOXSIZE;   // c2ray_parameters.f90:51
+constexpr int MAX_SUBBOX = C2R_PARAM_MAX_SUBBOX; // c2ray_parameters.f90:56
 
 // mathconstants.f90:21, abundances.f90:23-29
 constexpr double pi = C2R_F(3.141592654);
-constexpr double abu_he = C2R_F(0.074);
-constexpr double abu_c = C2R_F(7.1e-7);
+constexpr double abu_he = C2R_FX(C2R_PARAM_ABU_HE);
+constexpr double abu_c = C2R_FX(C2R_PARAM_ABU_C);
 // cgsconstants.f90:26-103
 constexpr double hplanck = 6.6260755e-27;
 constexpr double k_B = 1.381e-16;
@@ -75,12 +113,12 @@ constexpr double gamma1 = 5.0 / 3.0 - 1.0;
 constexpr double ion_freq_HI = ev2fr * eth0;
 constexpr double ion_freq_HeI = ev2fr * ethe0;
 // c2ray_parameters.f90:26-89
-constexpr double epsilon = 1.0e-20;
-constexpr double convergence_fraction = C2R_F(2.5e-4);
-constexpr double minimum_fractional_change = C2R_F(1.0e-2);
-constexpr double minimum_fraction_of_atoms = C2R_F(1.0e-8);
-constexpr double minitemp = C2R_F(1.0);
-constexpr double relative_denergy = C2R_F(0.1);
+constexpr double epsilon = C2R_PARAM_EPSILON;
+constexpr double convergence_fraction = C2R_FX(C2R_PARAM_CONVERGENCE_FRACTION);
+constexpr double minimum_fractional_change = C2R_FX(C2R_PARAM_MINIMUM_FRACTIONAL_CHANGE);
+constexpr double minimum_fraction_of_atoms = C2R_FX(C2R_PARAM_MINIMUM_FRACTION_OF_ATOMS);
+constexpr double minitemp = C2R_FX(C2R_PARAM_MINITEMP);
+constexpr double relative_denergy = C2R_FX(C2R_PARAM_RELATIVE_DENERGY);
 // cgsphotoconstants.f90:25-50
 constexpr double sigma_HI_at_ion_freq = C2R_F(6.346e-18);
 constexpr double sigma_HeI_at_ion_freq = C2R_F(7.430e-18);

@@ -36,13 +36,21 @@ static const double ethe0 = F(24.587), ethe1 = F(54.416);
 static const double ev2fr = F(0.241838e15);
 /* c2ray_parameters.f90:26-89 */
 static const double epsilon = 1.0e-20;
+#ifdef ORC_CONVERGENCE_FRACTION /* e.g. -DORC_CONVERGENCE_FRACTION=1.0e-3f: the REAL(4) literal of another c2ray_parameters.f90 */
+static const double convergence_fraction = (double)(ORC_CONVERGENCE_FRACTION);
+#else
 static const double convergence_fraction = F(2.5e-4);
+#endif
 static const double minimum_fractional_change = F(1.0e-2);
 static const double minimum_fraction_of_atoms = F(1.0e-8);
 static const double minitemp = F(1.0);
 static const double relative_denergy = F(0.1);
+#ifndef SUBBOXSIZE   /* c2ray_parameters.f90:51,56; -DSUBBOXSIZE=.. -DMAX_SUBBOX=..: the checker of a product build with other parameters */
 #define SUBBOXSIZE 10
+#endif
+#ifndef MAX_SUBBOX
 #define MAX_SUBBOX 1150
+#endif
 /* cgsphotoconstants.f90:25-50 */
 static const double sigma_HI_at_ion_freq = F(6.346e-18);
 static const double sigma_HeI_at_ion_freq = F(7.430e-18);

@@ -107,7 +107,11 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(str(build()))
+        # ORC_LIB_PATH: a build of the oracle with other compile-time parameters (oracle/Makefile: liboracle_params.so),
+        # the checker of a product library built with the same ones (tests/test_gpu_parity.py)
+        import os
+        alt = os.environ.get("ORC_LIB_PATH")
+        _lib = C.CDLL(alt if alt else str(build()))
         _lib.orc_coolin.restype = C.c_double
         _lib.orc_electrondens.restype = C.c_double
     return _lib

@@ -1287,3 +1287,66 @@ def test_scratch_of_a_time_step_is_sized_before_its_iterations(pkg, orc, otables
     for k, ref in (("phih_grid", s.phih), ("phihe_grid", s.phihe), ("xh_av", s.xh_av), ("xhe_av", s.xhe_av), ("xh_intermed", s.xh_intermed)):
         assert np.array_equal(got[k], ref), k
     assert got["sum_nbox"] == int(s.c.sum_nbox)
+
+
+_PARAMS_SNIPPET = r'''
+import sys, numpy as np, json
+sys.path.insert(0, "{root}"); sys.path.insert(0, "{root}/oracle")
+import __graft_entry__ as ge, oracle as orc
+pkg = ge.load_package()
+hp = pkg.hostphys
+import ctypes as C
+buf = (C.c_double * 32)()
+n = pkg._lib.load().c2r_get_constants(buf, 32)
+consts = list(buf[:n])
+mesh = (32, 32, 32)
+rng = np.random.default_rng(17)
+zred = 9.0
+dr, vol = hp.test_grid(32, zred)
+nc = 32 ** 3
+ndens = hp.test_density(zred) * np.exp(rng.normal(0.0, 0.5, nc))
+x = 10.0 ** rng.uniform(-3.5, -1.0, nc)
+xh = np.concatenate([1.0 - x, x]); xhe = np.concatenate([1.0 - x, 0.7 * x, 0.3 * x])
+srcpos = np.array([[5, 20, 16], [28, 3, 9], [16, 16, 16]], dtype=np.int32)
+flux = np.array([3.0e6, 2.0e3, 5.0e4])
+mat = pkg.Material(ndens, xh, xhe, None, True, 1.0e4, 1.0, hp.reccoef(1.0e4))
+grid = pkg.GridProps(mesh, dr, vol); src = pkg.SourceProps(srcpos, flux, 1.0e48); cosmo = pkg.Cosmology(zred, hp.H0, hp.Omega0)
+dt = 1.0e6 * hp.YEAR
+ev = pkg.Evolve(mesh, pkg.RadiationTables.load(), device=0)
+niter = ev.evolve3D(0.0, dt, 0, mat, grid, src, cosmo)
+with np.load(pkg.evolve.DEFAULT_TABLES) as t:
+    T = orc.Tables({{k: t[k] for k in t.files}})
+st = orc.Step(mesh, dr, vol, zred, hp.H0, hp.Omega0, True, 1.0e4, 1.0, srcpos, flux, 1.0e48, ndens, hp.reccoef(1.0e4))
+s = orc.State(st, xh, xhe, None)
+nref = orc.evolve3d(T, st, s, dt)
+r = ev.rates
+same = dict(niter=niter == nref, conv=ev.conv_flags == s.conv_flags, xh=bool(np.array_equal(mat.xh, s.xh)), xhe=bool(np.array_equal(mat.xhe, s.xhe)),
+            phih=bool(np.array_equal(r["phih_grid"], s.phih)), phihe=bool(np.array_equal(r["phihe_grid"], s.phihe)), nbox=int(r["sum_nbox"]) == int(s.c.sum_nbox))
+print(json.dumps(dict(consts=consts, niter=niter, sum_nbox=int(r["sum_nbox"]), same=same)))
+'''
+
+
+def test_library_built_for_other_parameters(pkg):
+    """Round-4 VERDICT: subboxsize, max_subbox, the convergence thresholds ... are constants of the device code; a host built
+    with another c2ray_parameters.f90 needs another library.  _build.build(params=...) (or C2R_PARAMS) makes it: here
+    subboxsize = 4, max_subbox = 9 (sub-boxes grow in steps of 4 cells and end 9 cells from the source), convergence_fraction
+    = 1.0e-3 -- c2r_get_constants reports them, and a whole evolve3D call equals, bit for bit, the oracle compiled with the same
+    three values (oracle/Makefile: liboracle_params.so); the default library on the same inputs sweeps more sub-boxes."""
+    import subprocess
+    alt = ROOT / "c2-ray3dm1d_helium_amd" / "libc2ray_hip_params.so"
+    orc_alt = ROOT / "oracle" / "liboracle_params.so"
+    if not alt.exists() or not orc_alt.exists():
+        pytest.skip("the parameter variants are built by __graft_entry__.build()")
+    out = {}
+    for tag, env in (("params", {"C2R_LIB_PATH": str(alt), "ORC_LIB_PATH": str(orc_alt)}), ("default", {})):
+        r = subprocess.run([sys.executable, "-c", _PARAMS_SNIPPET.format(root=str(ROOT))], env={**os.environ, **env}, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = json.loads(r.stdout.strip().splitlines()[-1])
+    dump(out, "params_variant.json")
+    for tag in out:
+        assert all(out[tag]["same"].values()), (tag, out[tag]["same"])
+    assert out["params"]["consts"][0] == 4.0 and out["params"]["consts"][1] == 9.0
+    assert out["params"]["consts"][5] == float(np.float32(1.0e-3)) and out["default"]["consts"][5] == float(np.float32(2.5e-4))
+    assert out["default"]["consts"][0] == 10.0 and out["default"]["consts"][1] == 1150.0
+    assert out["params"]["sum_nbox"] != out["default"]["sum_nbox"]
