@@ -522,8 +522,12 @@ def main():
             for key, path in (("pmc", PMC_SUMMARY), ("dropin", DROPIN_TIMING), ("reference_at_size", REFERENCE_AT_SIZE)):
                 d, same = stored_profile(path)
                 if d is not None:
-                    out["stored_profiles"][key] = {"file": str(path.relative_to(ROOT)), "source_sha16": d.get("source_sha16"),
-                                                   "same_sources_as_this_run": same}
+                    entry = {"file": str(path.relative_to(ROOT)), "source_sha16": d.get("source_sha16")}
+                    if key == "reference_at_size":
+                        entry["depends_on_sources"] = False    # a run of the REFERENCE: nothing of this library is in it
+                    else:
+                        entry["same_sources_as_this_run"] = same
+                    out["stored_profiles"][key] = entry
             # the product the north star describes -- the reference's Fortran driver with this library's modules linked
             # in (oracle/ref_build.sh 256 hip) -- on this very workload, by the drop-in's own clock; measured by
             # tools/time_dropin.py on a GPU box and stored (the driver's bench box has no reference sources to build the
