@@ -165,6 +165,17 @@ def main():
     for p in range(2):
         save(outdir, f"composed_heat16_2x2_fused_rank{p}", res[p])
 
+    # the whole convergence loop inside the library (c2r_evolve3d), four communicators of one process
+    e = engine(pkg, tables, heat16, [0] * 4)
+    e.comm_init_local()
+    niter, flags = e.evolve3d(heat16[5])
+    m = pkg.Material(ndens=heat16[1].ndens, xh=heat16[1].xh.copy(), xhe=heat16[1].xhe.copy(), temperature_grid=heat16[1].temperature_grid.copy())
+    e.download_state(m)
+    out = {**e.download_rates(), **e.download_iter_state(), "conv": np.array(flags), "niter": niter, "xh": m.xh, "xhe": m.xhe,
+           "temperature": m.temperature_grid}
+    e.close()
+    save(outdir, "multi_heat16_N4_evolve3d", out)
+
     tiles_iso = case_tiles64(pkg, True)
     save(outdir, "multi_tiles64iso_N3_fused", run_multi(pkg, tables, tiles_iso, 3, True, niter=2))
     tiles_heat = case_tiles64(pkg, False)

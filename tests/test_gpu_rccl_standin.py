@@ -145,6 +145,23 @@ def test_two_processes_of_two_devices_vs_oracle(pkg, standin, cases):
         same(np.load(out / f"composed_heat16_2x2_fused_rank{p}.npz"), ref, p)
 
 
+def test_whole_evolve3d_in_the_library_vs_oracle(pkg, standin, cases):
+    """c2r_evolve3d on a four-communicator context: the library's own convergence loop (evolve.F90:147-217) around the slab-wise
+    iteration, to convergence.  Same number of outer iterations as the oracle's loop with four ranks' association, same
+    non-converged count after every one of them, and the state c2r_end_step leaves (xh = xh_intermed, ...) bit for bit."""
+    out, _ = standin
+    _, cs = cases
+    got = np.load(out / "multi_heat16_N4_evolve3d.npz")
+    niter = int(got["niter"])
+    assert niter > 3
+    ref = oracle_ranks(pkg, cs["heat16"], static_shares(3, 4), niter)
+    same(got, ref, "evolve3d")
+    crit = min(int(np.float32(2.5e-4) * 16 ** 3), 3)                  # evolve.F90:147
+    conv = [int(x) for x in ref["conv"]]
+    assert conv[-1] < crit and all(not (c < crit and i + 1 > 1) for i, c in enumerate(conv[:-1])), conv   # ... and no earlier exit
+    assert np.array_equal(got["xh"], ref["xh_intermed"]) and np.array_equal(got["xhe"], ref["xhe_intermed"])
+
+
 def test_tile_list_launches_vs_oracle(pkg, standin, cases):
     """64^3, five sources of which some stop after their first sub-box: rates launches from tile lists (which clear the grids
     first instead of writing them), isothermal over three communicators of one process and with heating over two ranks with
