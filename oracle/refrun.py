@@ -45,17 +45,17 @@ def read_records(path, mmap=False) -> dict:
     return out
 
 
-def ref_binary(mesh: int, which: str = "tap", omp: bool = False, pl: bool = False, lls: bool = False) -> Path:
-    tag = f"N{mesh}" + ("_omp" if omp else "") + ("_pl" if pl else "") + ("_lls" if lls else "")
+def ref_binary(mesh: int, which: str = "tap", omp: bool = False, pl: bool = False, lls: bool = False, params: bool = False) -> Path:
+    tag = f"N{mesh}" + ("_omp" if omp else "") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_params" if params else "")
     return REFDIR / tag / f"C2Ray_3D_{which}"
 
 
 def run_reference(mesh: int, sources, *, T0=1e4, isothermal=True, steps_per_slice=1,
                   outputs_per_slice=1, which="tap", omp=False, name=None, threads=1,
-                  timeout=3600, keep=True, pl=False, lls=False, streams="0 1 1 0 0"):
+                  timeout=3600, keep=True, pl=False, lls=False, streams="0 1 1 0 0", params=False):
     """Run the reference; returns the run directory (results in <run>/results).
     sources: (i, j, k, S_BB) or, for the -DPL -DQUASARS build (pl=True), (i, j, k, S_BB, S_PL, S_QPL)."""
-    exe = ref_binary(mesh, which, omp, pl, lls)
+    exe = ref_binary(mesh, which, omp, pl, lls, params)
     if not exe.exists():
         raise FileNotFoundError(f"{exe} missing: run oracle/ref_build.sh {mesh} [omp] [pl] [lls]")
     name = name or f"run_N{mesh}_{'iso' if isothermal else 'heat'}_{len(sources)}src"

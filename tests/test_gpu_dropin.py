@@ -68,6 +68,10 @@ def _reference_snapshot(golden_name, run_reference):
     (False, "keepstate", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     # ... =2, for runs without output stream 3 (the only reader of phih_grid / phiheat on the host): no rate grid comes back
     (True, "keepstate2", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
+    # a host with ANOTHER c2ray_parameters.f90 (subboxsize = 4, max_subbox = 9, convergence_fraction = 1.0e-3; oracle/ref_build.sh
+    # 16 params) and the library built for the same values (libc2ray_hip_params.so): evolve_ini's comparison of the compiled
+    # constants passes, and the files are the reference's
+    (False, "params", [(8, 8, 8, 1e55), (2, 15, 4, 3e54), (16, 1, 9, 2e54)]),
     # the -DPL -DQUASARS build (the flags of the reference's production targets, Makefile:185-186,207-208)
     (False, True, [(8, 8, 8, 1e55, 3e54, 0.0), (2, 15, 4, 0.0, 2e54, 4e54), (16, 1, 9, 2e54, 0.0, 1e54)]),
 ])
@@ -94,20 +98,21 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         monkeypatch.setenv("C2RAY_HIP_KEEP_STATE", str(keep))
     steps = 2 if keep else 1
     streams = "0 1 0 0 0" if keep == 2 else "0 1 1 0 0"
+    pvar = pl == "params"
     lls, dogrid, pl = pl == "lls", pl == "dogrid", pl is True
     which_hip = "hip_dogrid" if dogrid else ("hip_bycell" if bycell else ("hip_bypoint" if bypoint else "hip"))
-    ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls), refrun.ref_binary(16, which_hip, pl=pl, lls=lls)
+    ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls, params=pvar), refrun.ref_binary(16, which_hip, pl=pl, lls=lls, params=pvar)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "") + (f"_keepstate{keep}" if keep else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "") + (f"_keepstate{keep}" if keep else "") + ("_params" if pvar else "")
     import make_golden_dropin
     if pl:
         assert sources == make_golden_dropin.PL_SOURCES and not iso     # what the fixture was made from
     s1 = _reference_snapshot("dropin_ref_heat_pl.json" if pl else None,
                              lambda: refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=steps, which="test",
-                                                          name=f"dropin_ref_{tag}", pl=pl, lls=lls, streams=streams))
+                                                          name=f"dropin_ref_{tag}", pl=pl, lls=lls, streams=streams, params=pvar))
     r2 = refrun.run_reference(16, sources, isothermal=iso, steps_per_slice=steps, which=which_hip, name=f"dropin_hip_{tag}", pl=pl, lls=lls,
-                              streams=streams)
+                              streams=streams, params=pvar)
     s2 = json.loads(json.dumps(make_golden_dropin.snapshot(r2)))
     assert len(s1["sha256"]) >= (9 if keep == 2 else 15), sorted(s1["sha256"])
     # every output file byte for byte (SHA-256 of the reference's file against the drop-in's)
