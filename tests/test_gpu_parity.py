@@ -386,8 +386,18 @@ def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
         got = {"xh": xh, "xhe": xhe, "temperature": temp, **ev.rates, **ev.iter_state}
         for k in ["xh", "xhe", "phih_grid", "phihe_grid", "xh_av", "xhe_av"] + ([] if iso else ["temperature", "phiheat"]):
             assert sha(got[k]) == str(g("sha_" + k)), (call, k)
-        if f"c{call}_photon_loss" in z.files:   # (fixtures written from round 5 on) a sum whose order differs: to rounding
-            assert abs(ev.photon_loss_all[0] / float(g("photon_loss")[0]) - 1) <= 1e-13
+        if f"c{call}_photon_loss" in z.files:   # (fixtures written from round 5 on)
+            ratio = ev.photon_loss_all[0] / float(g("photon_loss")[0])
+            if "reference_build" in z.files:
+                # The reference's OpenMP build LOSES UPDATES of this one number: evolve0D adds to photon_loss_src_thread(tn)
+                # with the module variable tn of evolve_data (evolve_point.F90:58,312), which do_source's
+                # "!$omp parallel private(tn)" (evolve_source.F90:158) does not privatise in that scope -- every thread adds
+                # to the same element, unsynchronised.  Its photon_loss comes out a fraction of a per cent low (0.39 % here);
+                # nothing else reads it (add_photon_losses = .false.), and every grid above is bit-identical.
+                assert 1.0 <= ratio < 1.02, ratio
+                log[f"call{call}_photon_loss_over_openmp_reference"] = float(ratio)
+            else:                               # the serial build: a sum whose order differs, to rounding
+                assert abs(ratio - 1) <= 1e-13
         i0, j0, k0 = (int(x) - 1 for x in g("srcpos").reshape(-1, 3)[0])
         line = xh[nc:].reshape(n, n, n, order="F")[:, j0, k0]
         assert np.array_equal(line, g("xHII_line"))
@@ -1357,3 +1367,39 @@ def test_library_built_for_other_parameters(pkg):
     assert out["params"]["consts"][5] == float(np.float32(1.0e-3)) and out["default"]["consts"][5] == float(np.float32(2.5e-4))
     assert out["default"]["consts"][0] == 10.0 and out["default"]["consts"][1] == 1150.0
     assert out["params"]["sum_nbox"] != out["default"]["sum_nbox"]
+
+
+def test_density_rescaled_on_the_device_equals_the_hosts(pkg, tables, gold):
+    """c2r_scale_ndens + c2r_set_step_scalars (what the Fortran drop-in does under C2RAY_HIP_KEEP_STATE when cosmo_evol's
+    ndens = ndens / zfactor3 is all that happened to the density, cosmology.f90:193) against uploading the host's rescaled
+    array with c2r_set_step: one outer iteration, every grid bit for bit -- the device's division is the host's."""
+    i, _ = tap_case(gold("tap_N16_heat_3src.npz"), 1)
+    mesh, mat, grid, src, cosmo = make_inputs(pkg, i)
+    zfactor = (1.0 + 9.0) / (1.0 + 8.93)
+    zf3 = zfactor * zfactor * zfactor
+    mat2 = pkg.Material(ndens=mat.ndens / zf3, xh=mat.xh, xhe=mat.xhe, temperature_grid=mat.temperature_grid, isothermal=False,
+                        temper_val=mat.temper_val, clumping=mat.clumping, reccoef=mat.reccoef)
+    grid2 = pkg.GridProps(mesh, tuple(d * zfactor for d in grid.dr), grid.vol * zf3)
+    dt = float(i["dt"][0])
+    out = []
+    for on_device in (False, True):
+        e = engine_for(pkg, mesh, mat if on_device else mat2, grid if on_device else grid2, src, cosmo, tables)
+        if on_device:
+            e.scale_ndens(zf3)
+            e.set_step_scalars(mat2, grid2, cosmo)
+        e.begin_step()
+        e.set_rates_to_zero()
+        e.pass_sources(1, 1)
+        conv = e.global_pass(dt)
+        out.append({**e.download_rates(), **e.download_iter_state(), "conv": conv})
+        e.close()
+    a, b = out
+    assert a["conv"] == b["conv"] and a["sum_nbox"] == b["sum_nbox"]
+    for k in ("phih_grid", "phihe_grid", "phiheat", "xh_av", "xhe_av", "xh_intermed", "xhe_intermed"):
+        assert np.array_equal(a[k], b[k]), k
+    with pytest.raises(pkg.C2RayHipError):
+        e2 = pkg.HipEngine(mesh, 0)
+        try:
+            e2.scale_ndens(2.0)        # nothing on the device yet
+        finally:
+            e2.close()
