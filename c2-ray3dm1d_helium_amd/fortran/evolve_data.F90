@@ -6,9 +6,9 @@
 !! them); coldensh_out etc. are scratch of the reference's CPU sweep and have no host mirror.
 module evolve_data
 
-  use, intrinsic :: iso_c_binding, only: c_ptr, c_null_ptr, c_int, c_char, c_double
+  use, intrinsic :: iso_c_binding, only: c_ptr, c_null_ptr, c_int, c_char, c_double, c_null_char
   use c2ray_hip, only: c2r_create, c2r_create_multi, c2r_error_text, c2r_device_count, c2r_get_constants
-  use c2ray_hip, only: c2r_comm_unique_id, c2r_comm_init, c2r_comm_init_local
+  use c2ray_hip, only: c2r_comm_unique_id, c2r_comm_init, c2r_comm_init_local, c2r_comm_kind, c2r_comm_library
   use file_admin, only: logf
   use my_mpi                                  ! rank, npr, MPI_COMM_NEW
   use precision, only: dp
@@ -133,9 +133,9 @@ contains
   !! rank 0 to the others once.
   subroutine setup_communicator ()
 
-    character(kind=c_char) :: id(128)
+    character(kind=c_char) :: id(128), libpath(1024)
     integer(c_int) :: ierr
-    integer :: force
+    integer :: force, nchar
 #ifdef MPI
     integer :: mympierror
 #endif
@@ -155,6 +155,21 @@ contains
     elseif (hip_ndevices > 1) then
        ierr = c2r_comm_init_local (hip_ctx)
        if (ierr /= 0) call stop_with (c2r_error_text(hip_ctx))
+       if (rank == 0) then
+          if (c2r_comm_kind (hip_ctx) == 1) then
+             libpath = c_null_char
+             ierr = c2r_comm_library (libpath, int(size(libpath), c_int))
+             nchar = 0
+             do while (nchar < size(libpath))
+                if (libpath(nchar+1) == c_null_char) exit
+                nchar = nchar + 1
+             enddo
+             write(logf,"(A)") " evolve_ini: the sum over the devices is an ncclAllReduce of"
+             write(logf,"(2A)") "   ", transfer(libpath(1:nchar), repeat(" ", nchar))
+          else
+             write(logf,"(A)") " evolve_ini: one device for all: their sum is made by the library itself"
+          endif
+       endif
     else
        ! C2RAY_HIP_FORCE_COMM=1: a communicator of one rank, so that a one-GPU run goes through the very calls
        ! (ncclCommInitRank, ncclAllReduce) a multi-rank run makes

@@ -61,6 +61,10 @@ def _reference_snapshot(golden_name, run_reference):
     # sweeping one of the two sources, the in-process sum over the replicas, replicated chemistry.  Two sources
     # over two ranks add up as (0 + s1) + s2 either way: still byte-identical files
     (False, "ngpu2", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
+    # ... and the same with the sums carried by the library's RCCL path (comm_kind 1: ncclCommInitAll, grouped ncclAllReduce
+    # per slab, c2r_iteration) through the one-device stand-in for librccl of tests/fake_rccl.hip (C2R_RCCL_LIBRARY,
+    # C2R_COMM_SHARED_DEVICE_RCCL=1): the Fortran driver on "two GPUs" whose sum is not the in-process one
+    (False, "ngpu2_standin", [(8, 8, 8, 1e55), (2, 15, 4, 3e54)]),
     # C2RAY_HIP_KEEP_STATE=1 (opt-in): from the second evolve3D call on xh, xhe, temperature_grid stay on the device when a
     # sample of the host arrays still shows what the previous call downloaded, ndens is divided by cosmo_evol's zfactor**3 on
     # the device when that is all that happened to it (two time steps per slice: the step inside a slice), sent otherwise
@@ -82,10 +86,17 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     devtables = pl == "devtables"
     if pl == "comm1":
         monkeypatch.setenv("C2RAY_HIP_FORCE_COMM", "1")
-    if pl == "ngpu2":
+    if pl in ("ngpu2", "ngpu2_standin"):
         monkeypatch.setenv("C2RAY_HIP_NGPU", "2")
         monkeypatch.setenv("C2RAY_HIP_SAME_DEVICE", "1")
-    comm1, ngpu2 = pl == "comm1", pl == "ngpu2"
+    standin = pl == "ngpu2_standin"
+    if standin:
+        fake = ROOT / "tests" / "_fake_rccl.so"
+        if not fake.exists():
+            pytest.skip("tests/_fake_rccl.so is built by __graft_entry__.build() / tests/test_gpu_rccl_standin.py")
+        monkeypatch.setenv("C2R_RCCL_LIBRARY", str(fake))
+        monkeypatch.setenv("C2R_COMM_SHARED_DEVICE_RCCL", "1")
+    comm1, ngpu2 = pl == "comm1", pl in ("ngpu2", "ngpu2_standin")
     bycell = pl == "bycell"
     bypoint = pl == "bypoint"
     if bypoint:
@@ -104,7 +115,7 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
     ref, hip = refrun.ref_binary(16, "test", pl=pl, lls=lls, params=pvar), refrun.ref_binary(16, which_hip, pl=pl, lls=lls, params=pvar)
     if not ref.exists() or not hip.exists():
         pytest.skip("oracle/_ref binaries not present (built only where /root/reference exists)")
-    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "") + (f"_keepstate{keep}" if keep else "") + ("_params" if pvar else "")
+    tag = ("iso" if iso else "heat") + ("_pl" if pl else "") + ("_lls" if lls else "") + ("_dogrid" if dogrid else "") + ("_devtables" if devtables else "") + ("_comm1" if comm1 else "") + ("_ngpu2" if ngpu2 else "") + ("_standin" if standin else "") + ("_bycell" if bycell else "") + ("_stepwise" if stepwise else "") + ("_bypoint" if bypoint else "") + (f"_keepstate{keep}" if keep else "") + ("_params" if pvar else "")
     import make_golden_dropin
     if pl:
         assert sources == make_golden_dropin.PL_SOURCES and not iso     # what the fixture was made from
@@ -133,6 +144,10 @@ def test_reference_driver_with_hip_evolve_writes_identical_files(iso, pl, source
         assert "RCCL communicator of one rank" in log2
     if ngpu2:
         assert "devices per rank:   2" in log2
+        if standin:
+            assert "the sum over the devices is an ncclAllReduce of" in log2 and "_fake_rccl.so" in log2
+        else:
+            assert "their sum is made by the library itself" in log2
     if stepwise or dogrid or bycell or bypoint:
         assert "outer iterations call by call" in log2
     else:
