@@ -47,8 +47,8 @@ COLUMN_BYTES_PER_CELL_SOURCE = 88.0   # column sweep alone: 40 B state + 48 B co
 CHEM_BYTES_PER_CELL = 252.0           # SURVEY.md section 8(d), isothermal chemistry pass
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6               # MI355X_MICROARCH.md: 16 384 FP64 lanes x 2.4 GHz x 2 (vector; the matrix peak is the same)
-PMC_SUMMARY = ROOT / "profiles" / "r04_bench_pmc_summary.json"
-DROPIN_TIMING = ROOT / "profiles" / "r04_dropin_timing.json"
+PMC_SUMMARY = ROOT / "profiles" / "r05_bench_pmc_summary.json"
+DROPIN_TIMING = ROOT / "profiles" / "r05_dropin_timing.json"
 REFERENCE_AT_SIZE = ROOT / "profiles" / "r04_reference_256_gpubox.json"   # timed on a GPU box's host cores (tools/time_reference.py)
 
 

@@ -1565,10 +1565,12 @@ struct c2r_ctx {
   };
   std::vector<Segment> segs[2];
   size_t seg_cur[2] = {0, 0}, seg_used[2] = {0, 0}; // bump allocation within a batch
+  std::vector<Segment> vacated[2];                  // blocks whose source moved to a deeper one in this batch: reused first
   size_t arena_total = 0;                          // doubles in all segments
   std::vector<int> prev_nbox;      // per source: sub-boxes of the last pass (0: unknown), sizes the next block
   std::vector<int> prev_grow;      // per source: by how many sub-boxes its box grew from the pass before last to the last one
   int last_first = 0, last_stride = 0; // the share of the sources the last pass swept: first, first + stride, ... (arena_prepare plans the next step's scratch for it)
+  bool arena_reserved = false;     // C2R_ARENA_RESERVE_GB has been looked at (first c2r_begin_step)
   bool in_pass = false;            // pass_list is running (arena statistics: allocations that land inside an iteration)
   long long arena_stats[5] = {0, 0, 0, 0, 0}; // segments allocated, of them inside a pass, doubles allocated, block moves, batch restarts
   SrcDev *d_src[2] = {nullptr, nullptr}, *h_src[2] = {nullptr, nullptr}; // source records of the two sets (h: pinned)
@@ -1752,6 +1754,19 @@ static size_t block_doubles(int cap) { // doubles of a column block that holds s
 // per GB on this system, which is why nothing is allocated ahead of need.  `hint`: what the caller knows it will ask
 // for in all (a new segment is made that large if the device has the room).
 static double *arena_alloc(c2r_ctx *c, int set, size_t n, size_t hint = 0) {
+  // a place some source of this batch has moved out of (its stream order protects it: whatever read or copied the old
+  // block was queued on the sweep stream before anything the new owner will queue): the smallest that fits
+  {
+    std::vector<c2r_ctx::Segment> &v = c->vacated[set];
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i].n >= n && (best == v.size() || v[i].n < v[best].n)) best = i;
+    if (best < v.size()) {
+      double *p = v[best].p;
+      v.erase(v.begin() + (long)best);
+      return p;
+    }
+  }
   for (;;) {
     if (c->seg_cur[set] < c->segs[set].size()) {
       c2r_ctx::Segment &sg = c->segs[set][c->seg_cur[set]];
@@ -1779,7 +1794,11 @@ static double *arena_alloc(c2r_ctx *c, int set, size_t n, size_t hint = 0) {
     // C2R_ARENA_MIN_SEGMENT_MB (tests): a smaller floor than 2 GB, so that small meshes reach the growth paths
     size_t floor_doubles = (size_t)1 << 28;
     if (const char *e = getenv("C2R_ARENA_MIN_SEGMENT_MB")) floor_doubles = std::max<size_t>(1024, (size_t)(atof(e) * 1.0e6 / sizeof(double)));
-    const size_t want = std::min(room, std::max(std::max(n, hint), std::max(have / 2, floor_doubles)));
+    // ... and a ceiling on the geometric growth: on this system a device allocation is free up to some tens of GB and
+    // costs ~20 ms per GB beyond (0.97 s for a 45 GB segment, round 5), inside whatever iteration needs it
+    size_t ceil_doubles = (size_t)2 << 30; // 16 GB
+    if (const char *e = getenv("C2R_ARENA_MAX_SEGMENT_GB")) ceil_doubles = std::max<size_t>(floor_doubles, (size_t)(atof(e) * 1.0e9 / sizeof(double)));
+    const size_t want = std::min(room, std::max(std::max(n, hint), std::max(std::min(have / 2, ceil_doubles), floor_doubles)));
     c2r_ctx::Segment sg;
     const auto t0 = std::chrono::steady_clock::now();
     if (hipMalloc(&sg.p, sizeof(double) * want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -1808,6 +1827,7 @@ static void arena_release(c2r_ctx *c, int set) {
     if (c->last_cols >= sg.p && c->last_cols < sg.p + sg.n) c->last_cols = nullptr;
   }
   c->segs[set].clear();
+  c->vacated[set].clear();
   c->seg_cur[set] = c->seg_used[set] = 0;
   if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d released, %.2f GB left in all\n", set, c->arena_total * 8e-9);
 }
@@ -2503,6 +2523,29 @@ static int predicted_shells(const c2r_ctx *c, int ns) {
 }
 
 static int arena_prepare(c2r_ctx *c) {
+  // C2R_ARENA_RESERVE_GB="a[,b]": column scratch of set 0 (and set 1) made when the FIRST step begins, for hosts that know
+  // what their source lists will need.  A device allocation beyond the first tens of GB costs ~24 ms per GB on this system
+  // and stalls every launch of the process while it lasts, whichever thread makes it (tools/micro/malloc_overlap.hip,
+  // profiles/r05_malloc_overlap.txt: 0.97 s for 40 GB, the kernel stream of another thread idle for all of it): it can be
+  // moved, not hidden -- this moves it in front of the first iteration.
+  if (!c->arena_reserved) {
+    c->arena_reserved = true;
+    if (const char *e = getenv("C2R_ARENA_RESERVE_GB")) {
+      double gb[2] = {0.0, 0.0};
+      const int n = sscanf(e, "%lf,%lf", &gb[0], &gb[1]);
+      for (int set = 0; set < 2 && set < std::max(n, 0); set++) {
+        const size_t want = (size_t)(gb[set] * 1.0e9 / sizeof(double));
+        size_t have = 0;
+        for (const c2r_ctx::Segment &sg : c->segs[set]) have += sg.n;
+        if (want > have) {
+          c->seg_cur[set] = c->segs[set].size(); // a new segment, whatever the existing ones have free
+          c->seg_used[set] = 0;
+          (void)arena_alloc(c, set, want - have, want - have);
+          c->seg_cur[set] = c->seg_used[set] = 0;
+        }
+      }
+    }
+  }
   if (c->last_stride < 1 || c->prev_nbox.size() != (size_t)c->nsrc) return 0;
   std::vector<int> mine; // this context's share, as the last pass had it (do_grid_static: first = 1 + rank, stride = ranks)
   for (int ns = c->last_first; ns <= c->nsrc; ns += c->last_stride) mine.push_back(ns);
@@ -2881,6 +2924,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
       for (bool released = false;;) {
         c->seg_cur[set] = 0;
         c->seg_used[set] = 0;
+        c->vacated[set].clear();
         SrcDev *hs = c->h_src[set];
         size_t total = 0;
         for (int b = 0; b < nb; b++) total += block_doubles(predicted_cap(mine[b0 + b]));
@@ -3075,6 +3119,7 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
                                      hipMemcpyDeviceToDevice, c->stream));
           }
         }
+        if (S.cz > 0) c->vacated[set].push_back(c2r_ctx::Segment{S.cols, 6 * S.cz}); // free for the batch's later moves
         S.cols = ncols;
         S.cz = ncz;
         r.cap = ncap;

@@ -141,7 +141,10 @@ def main():
     e.enable_timing(True)
     dt = a.dt_years * pkg.hostphys.YEAR
     mine = len(range(a.rank, a.sources, a.ranks))
-    e.begin_step()
+    t_begin = time.perf_counter()
+    e.begin_step()            # with C2R_ARENA_RESERVE_GB: the column scratch is allocated here, in front of the iterations
+    e.synchronize()
+    t_begin = time.perf_counter() - t_begin
     conv_criterion = min(int(2.5e-4 * n ** 3), a.sources)
     hist = []
     t_all = time.perf_counter()
@@ -195,7 +198,8 @@ def main():
     out = {"tables_s": t_tab,
            "workload": f"configs[{4 if a.config5 else 3}]-like{' (heating, BB + PL + QPL SEDs, device-built tables)' if a.config5 else ''}: {n}^3 log-normal density, {a.sources} sources, rank {a.rank} of {a.ranks} "
                        f"({mine} sources on this GPU), neutral start, dt = {a.dt_years:g} yr, batch {a.batch}",
-           "niter": niter, "wall_s": wall, "swept_cell_updates_per_s": swept / wall,
+           "niter": niter, "wall_s": wall, "begin_step_s": t_begin, "arena_reserve_gb": __import__("os").environ.get("C2R_ARENA_RESERVE_GB"),
+           "arena": e.arena_stats(), "swept_cell_updates_per_s": swept / wall,
            "nominal_cell_updates_per_s": n ** 3 * mine * niter / wall,
            "mean_subboxes_per_source": float(np.mean([h["sum_nbox"] for h in hist])) / max(1, mine),
            "iterations": hist}
