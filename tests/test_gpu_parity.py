@@ -1403,3 +1403,36 @@ def test_density_rescaled_on_the_device_equals_the_hosts(pkg, tables, gold):
             e2.scale_ndens(2.0)        # nothing on the device yet
         finally:
             e2.close()
+
+
+def test_scratch_reserved_before_the_first_iteration(pkg, tables, monkeypatch):
+    """C2R_ARENA_RESERVE_GB: a host that knows what its source lists will need has the column scratch allocated when the first
+    step begins (a cold device allocation costs ~24 ms per GB and stalls the whole process): the passes of a
+    FIRST step then allocate nothing, and the results are those of a run that grew its scratch as it went."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import rccl_standin_worker as w
+    monkeypatch.setenv("C2R_ARENA_MIN_SEGMENT_MB", "8")
+    case = w.case_tiles64(pkg, True)
+    mesh, mat, grid, src, cosmo, dt = case
+    out = []
+    for reserve in (None, "0.25"):
+        if reserve:
+            monkeypatch.setenv("C2R_ARENA_RESERVE_GB", reserve)
+        e = engine_for(pkg, mesh, mat, grid, src, cosmo, tables)
+        e.begin_step()
+        at_begin = e.arena_stats()
+        for _ in range(2):
+            e.set_rates_to_zero()
+            e.pass_sources(1, 1)
+            e.global_pass(dt)
+        st = e.arena_stats()
+        out.append({**e.download_rates(), **e.download_iter_state()})
+        e.close()
+        if reserve:
+            assert at_begin["segments"] == 1 and at_begin["doubles_held"] >= 0.25e9 / 8, at_begin
+            assert st["segments"] == 1 and st["segments_in_pass"] == 0 and st["batch_restarts"] == 0, st
+        else:
+            assert at_begin["segments"] == 0 and st["segments_in_pass"] >= 1, (at_begin, st)
+    for k in ("phih_grid", "phihe_grid", "xh_av", "xhe_av", "xh_intermed", "xhe_intermed"):
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert out[0]["sum_nbox"] == out[1]["sum_nbox"]
