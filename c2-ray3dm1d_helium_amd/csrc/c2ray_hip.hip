@@ -2519,7 +2519,9 @@ static StepScalars scalars(c2r_ctx *c) {
 static int predicted_shells(const c2r_ctx *c, int ns) {
   const int prev = c->prev_nbox[(size_t)ns - 1];
   const int grow = c->prev_grow.size() == c->prev_nbox.size() ? c->prev_grow[(size_t)ns - 1] : 0;
-  return std::min(c->g.smax, SUBBOXSIZE * (prev > 0 ? prev + std::max(1, 2 * grow) : 4));
+  const int cap = std::min(c->g.smax, SUBBOXSIZE * (prev > 0 ? prev + std::max(1, 2 * grow) : 4));
+  // within a fifth of the mesh limit: the limit (a block less than twice as large, and never a move)
+  return 5 * cap >= 4 * c->g.smax ? c->g.smax : cap;
 }
 
 static int arena_prepare(c2r_ctx *c) {
@@ -2950,8 +2952,22 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           continue;
         }
         if (placed == 0) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
-        if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d: batch of %d cut to the %d sources that fit\n", set, nb, placed);
-        nb = placed; // the same calls place the same blocks again
+        // A batch cut to exactly what fits has no room for a source that outgrows its block (the deeper block is needed
+        // while the old one is still in use) and starts over at the first such move -- at 512^3, where a block at the mesh
+        // limit is 6.4 GB and a set holds some twenty, 615 times in six passes (round 5).  So the cut leaves room for a third
+        // of the sources that can still grow to move once; sources at the mesh limit need none.
+        int keep = placed;
+        for (;;) {
+          size_t used = 0, reserve = 0;
+          for (int b = 0; b < keep; b++) {
+            used += 6 * hs[b].cz;
+            if (run[b].cap < g.smax) reserve += block_doubles(std::min(g.smax, 2 * run[b].cap));
+          }
+          if (keep <= 1 || used + reserve / 3 <= placed_doubles) break;
+          keep--;
+        }
+        if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d: batch of %d cut to %d sources (%d fit)\n", set, nb, keep, placed);
+        nb = keep; // the same calls place the same blocks again
         run.resize((size_t)nb);
       }
       SrcDev *hs = c->h_src[set];
@@ -3093,9 +3109,12 @@ static int pass_list(c2r_ctx *c, const std::vector<int> &mine, int nslab = 0) {
           // that did not fit, with fewer sources.
           HIPCHK(c, hipStreamSynchronize(c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream_probe));
+          // (round 5: a source still growing when the room ran out is given the mesh limit, not two rounds more -- at 512^3
+          // the fronts of a whole batch race there together, and "two more" made every batch start over twice)
+          const int limit_rounds = (g.smax + SUBBOXSIZE - 1) / SUBBOXSIZE;
           for (int b = 0; b < nb; b++) {
             int &pn = c->prev_nbox[(size_t)run[b].ns - 1];
-            pn = std::max(pn, run[b].active ? run[b].nbox + 2 : run[b].nbox);
+            pn = std::max(pn, run[b].active ? limit_rounds : run[b].nbox);
           }
           if (nb == 1) return fail(c, "column scratch: one source of this mesh does not fit in device memory");
           if (getenv("C2R_ARENA_LOG")) fprintf(stderr, "c2ray_hip: column scratch, set %d: no room to grow in round %d, batch of %d starts over\n", set, round, nb);
