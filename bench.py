@@ -305,6 +305,10 @@ def main():
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if a.gpus != world:
             raise SystemExit(f"bench.py --gpus {a.gpus} inside a launch of WORLD_SIZE={world}")
+        # C2R_BENCH_SHARE_DEVICE=1 under a launcher: every rank on GPU 0 -- a rehearsal of this very launch shape on a one-GPU
+        # box, possible only with a stand-in for RCCL that accepts it (C2R_RCCL_LIBRARY; the line then says STAND-IN)
+        if os.environ.get("C2R_BENCH_SHARE_DEVICE"):
+            local = 0
         devices = local
     torch.cuda.set_device(local)
     dist = None

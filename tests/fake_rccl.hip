@@ -25,7 +25,12 @@
 //                             ncclRemoteError
 //   ncclCommDestroy, ncclGetErrorString
 //
-// Ranks live in one process (threads, or one thread for all): no inter-process transport.  A rank that never arrives
+// FAKE_RCCL_MULTIPROCESS=1: ranks in SEVERAL PROCESSES on the one device, one communicator per process -- the launch shape of
+// torch.distributed.run / MPI (ncclGetUniqueId names a POSIX shared-memory block; ncclCommInitRank maps it).  Collectives are
+// then fully host-synchronous: a rank waits for its stream, announces its buffers (hipIpcGetMemHandle), the last to arrive
+// maps the others' buffers (hipIpcOpenMemHandle), runs the same rank-ordered sum, waits for it, and lets everybody go.  No
+// overlap of anything -- it exercises control flow and data flow between processes, nothing else.
+// Otherwise ranks live in one process (threads, or one thread for all).  A rank that never arrives
 // makes the others give up after FAKE_RCCL_TIMEOUT_S seconds (default 60) with ncclSystemError -- a test fails, it
 // does not hang.  FAKE_RCCL_HANG=1: a rank whose peers are missing (or whose clique was aborted by another rank) does
 // NOT get an error: the call returns ncclSuccess and the caller's stream is left waiting behind a host function that
@@ -49,6 +54,11 @@
 #include <unistd.h>
 #include <vector>
 
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+
 namespace {
 
 constexpr int MAXR = 16;
@@ -67,7 +77,12 @@ __global__ void __launch_bounds__(256) k_sum_rank_order(Ptrs p, int n, size_t co
 }
 
 struct Clique;
+struct ShmClique;
 struct Comm {
+  ShmClique *mp = nullptr; // FAKE_RCCL_MULTIPROCESS: the clique lives in shared memory
+  std::string mp_name;
+  int mp_n = 0;
+  unsigned long long mp_seq = 0;
   std::shared_ptr<Clique> q;
   int rank = 0, device = 0;
   unsigned long long seq = 0; // collectives issued on this communicator
@@ -79,6 +94,8 @@ struct Comm {
   int hangs = 0;
   hipStream_t hang_stream = nullptr;
 };
+
+ncclResult_t mp_retire(Comm *c, bool abort); // (multi-process mode, below)
 
 struct Op {
   int arrived = 0, released = 0;
@@ -226,6 +243,7 @@ void free_clique(Clique &q) {
 
 ncclResult_t retire(Comm *c, bool abort) {
   if (!c || c->gone) return ncclInvalidArgument;
+  if (c->mp) return mp_retire(c, abort);
   std::shared_ptr<Clique> q = c->q;
   {
     std::lock_guard<std::mutex> lk(c->hm);
@@ -259,6 +277,171 @@ ncclResult_t retire(Comm *c, bool abort) {
   return ncclSuccess; // the Comm itself is leaked on purpose: a late call on it must find `gone`, not freed memory
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ranks in several processes (FAKE_RCCL_MULTIPROCESS=1)
+struct ShmRank {
+  hipIpcMemHandle_t send_h, recv_h;
+  size_t send_off, recv_off;
+};
+struct ShmClique {
+  pthread_mutex_t m;
+  pthread_cond_t cv;
+  int n, joined, gone, broken;
+  unsigned long long seq; // the collective in progress
+  int arrived, left, done, status;
+  size_t count;
+  ShmRank r[MAXR];
+};
+
+bool multiprocess_mode() {
+  const char *e = getenv("FAKE_RCCL_MULTIPROCESS");
+  return e && atoi(e) > 0;
+}
+
+// cond wait with the stand-in's time-out; false when time is up
+bool mp_wait(ShmClique *q, double seconds) {
+  timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  const long long ns = (long long)(seconds * 1e9) + ts.tv_nsec;
+  ts.tv_sec += ns / 1000000000LL;
+  ts.tv_nsec = ns % 1000000000LL;
+  return pthread_cond_timedwait(&q->cv, &q->m, &ts) == 0;
+}
+
+ncclResult_t mp_export(const void *p, hipIpcMemHandle_t *h, size_t *off) {
+  static std::mutex m;
+  static std::map<void *, hipIpcMemHandle_t> cache; // one handle per allocation
+  void *base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) return ncclUnhandledCudaError;
+  std::lock_guard<std::mutex> lk(m);
+  auto it = cache.find(base);
+  if (it == cache.end()) {
+    hipIpcMemHandle_t hh;
+    if (hipIpcGetMemHandle(&hh, base) != hipSuccess) return ncclUnhandledCudaError;
+    it = cache.emplace(base, hh).first;
+  }
+  *h = it->second;
+  *off = (size_t)(static_cast<const char *>(p) - static_cast<const char *>(base));
+  return ncclSuccess;
+}
+
+void *mp_import(const hipIpcMemHandle_t &h, size_t off) {
+  static std::mutex m;
+  static std::map<std::string, void *> cache; // a peer's allocation, mapped once
+  const std::string key(reinterpret_cast<const char *>(&h), sizeof h);
+  std::lock_guard<std::mutex> lk(m);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return nullptr;
+    it = cache.emplace(key, p).first;
+  }
+  return static_cast<char *>(it->second) + off;
+}
+
+ncclResult_t mp_allreduce(Comm *c, const void *sendbuff, void *recvbuff, size_t count, hipStream_t stream) {
+  ShmClique *q = c->mp;
+  DeviceGuard g(c->device);
+  if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError; // my input is complete
+  ShmRank mine;
+  ncclResult_t rc = mp_export(sendbuff, &mine.send_h, &mine.send_off);
+  if (rc == ncclSuccess) rc = mp_export(recvbuff, &mine.recv_h, &mine.recv_off);
+  if (rc != ncclSuccess) return rc;
+  const unsigned long long seq = c->mp_seq++;
+  pthread_mutex_lock(&q->m);
+  g_stats[1]++;
+  // the slot of the collective before this one must have been left by everybody
+  while (!q->broken && q->seq != seq)
+    if (!mp_wait(q, timeout_s())) { pthread_mutex_unlock(&q->m); return ncclSystemError; }
+  if (q->broken) { pthread_mutex_unlock(&q->m); return ncclRemoteError; }
+  if (q->arrived == 0) { q->count = count; q->done = 0; q->status = 0; }
+  if (q->count != count) { q->broken = 1; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->m); return ncclInvalidArgument; }
+  q->r[c->rank] = mine;
+  if (++q->arrived == q->n) {
+    // everybody's input is complete and announced: the sum, here, now
+    Ptrs p{};
+    bool ok = true;
+    for (int r = 0; r < q->n && ok; r++) {
+      if (r == c->rank) {
+        p.s[r] = static_cast<const double *>(sendbuff);
+        p.r[r] = static_cast<double *>(recvbuff);
+      } else {
+        p.s[r] = static_cast<const double *>(mp_import(q->r[r].send_h, q->r[r].send_off));
+        p.r[r] = static_cast<double *>(mp_import(q->r[r].recv_h, q->r[r].recv_off));
+        ok = p.s[r] && p.r[r];
+      }
+    }
+    if (ok && count > 0) {
+      const int nblk = (int)std::min<size_t>(8192, (count + 255) / 256);
+      hipLaunchKernelGGL(k_sum_rank_order, dim3(nblk), dim3(256), 0, stream, p, q->n, count);
+      ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+    }
+    q->status = ok ? 0 : 1;
+    q->done = 1;
+    g_stats[2]++;
+    pthread_cond_broadcast(&q->cv);
+  } else {
+    while (!q->done && !q->broken)
+      if (!mp_wait(q, timeout_s())) { q->broken = 1; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->m); return ncclSystemError; }
+  }
+  const bool bad = q->broken || q->status != 0;
+  if (++q->left == q->n) { // the last one out frees the slot for the next collective
+    q->arrived = q->left = 0;
+    q->seq++;
+    pthread_cond_broadcast(&q->cv);
+  }
+  pthread_mutex_unlock(&q->m);
+  return bad ? (q->broken ? ncclRemoteError : ncclUnhandledCudaError) : ncclSuccess;
+}
+
+ncclResult_t mp_join(Comm *c, int nranks, const ncclUniqueId &id, int rank) {
+  const char *name = std::strchr(id.internal, '/');
+  if (!name) return ncclInvalidArgument;
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return ncclSystemError;
+  void *p = mmap(nullptr, sizeof(ShmClique), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return ncclSystemError;
+  ShmClique *q = static_cast<ShmClique *>(p);
+  c->mp = q;
+  c->mp_name = name;
+  c->mp_n = nranks;
+  c->rank = rank;
+  (void)hipGetDevice(&c->device);
+  pthread_mutex_lock(&q->m);
+  if (q->n == 0) q->n = nranks;
+  ncclResult_t rc = q->n == nranks ? ncclSuccess : ncclInvalidUsage;
+  if (rc == ncclSuccess) {
+    q->joined++;
+    pthread_cond_broadcast(&q->cv);
+    while (q->joined < q->n && !q->broken)
+      if (!mp_wait(q, timeout_s())) { rc = ncclSystemError; break; }
+    if (q->broken) rc = ncclRemoteError;
+  }
+  pthread_mutex_unlock(&q->m);
+  {
+    std::lock_guard<std::mutex> lk(g_m);
+    g_stats[0]++;
+    if (g_stats[3] < nranks) g_stats[3] = nranks;
+  }
+  return rc;
+}
+
+ncclResult_t mp_retire(Comm *c, bool abort) {
+  ShmClique *q = c->mp;
+  pthread_mutex_lock(&q->m);
+  if (abort) q->broken = 1;
+  const bool last = ++q->gone == q->n;
+  pthread_cond_broadcast(&q->cv);
+  pthread_mutex_unlock(&q->m);
+  if (last) shm_unlink(c->mp_name.c_str());
+  munmap(q, sizeof(ShmClique));
+  c->mp = nullptr;
+  c->gone = true;
+  return ncclSuccess;
+}
+
 } // namespace
 
 extern "C" {
@@ -273,6 +456,28 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
   if (!id) return ncclInvalidArgument;
   std::lock_guard<std::mutex> lk(g_m);
   std::memset(id->internal, 0, sizeof id->internal);
+  if (multiprocess_mode()) {
+    // the clique is a block of shared memory that this call makes and the last rank to leave removes
+    snprintf(id->internal, sizeof id->internal, "FAKE-RCCL-MP /fake_rccl_%d_%llu", (int)getpid(), ++g_ids);
+    const char *name = std::strchr(id->internal, '/');
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(ShmClique)) != 0) return ncclSystemError;
+    void *p = mmap(nullptr, sizeof(ShmClique), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return ncclSystemError;
+    ShmClique *q = static_cast<ShmClique *>(p);
+    std::memset(q, 0, sizeof *q);
+    pthread_mutexattr_t ma;
+    pthread_mutexattr_init(&ma);
+    pthread_mutexattr_setpshared(&ma, PTHREAD_PROCESS_SHARED);
+    pthread_mutex_init(&q->m, &ma);
+    pthread_condattr_t ca;
+    pthread_condattr_init(&ca);
+    pthread_condattr_setpshared(&ca, PTHREAD_PROCESS_SHARED);
+    pthread_cond_init(&q->cv, &ca);
+    munmap(q, sizeof(ShmClique));
+    return ncclSuccess;
+  }
   snprintf(id->internal, sizeof id->internal, "FAKE-RCCL clique %llu of process %d", ++g_ids, (int)getpid());
   return ncclSuccess;
 }
@@ -303,6 +508,11 @@ ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
   if (!comm || nranks < 1 || nranks > MAXR || rank < 0 || rank >= nranks) return ncclInvalidArgument;
   if (std::strncmp(id.internal, "FAKE-RCCL", 9) != 0) return ncclInvalidArgument; // an id of another library
+  if (std::strncmp(id.internal, "FAKE-RCCL-MP", 12) == 0) {
+    Comm *c = new Comm;
+    *comm = reinterpret_cast<ncclComm_t>(c);
+    return mp_join(c, nranks, id, rank); // (inside a group too: one communicator per process, nothing to defer)
+  }
   std::shared_ptr<Clique> q;
   {
     std::lock_guard<std::mutex> lk(g_m);
@@ -348,6 +558,11 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
   Comm *c = reinterpret_cast<Comm *>(comm);
   if (!c || c->gone || !sendbuff || !recvbuff) return ncclInvalidArgument;
   if (datatype != ncclFloat64 || op != ncclSum) return ncclInvalidArgument; // all the product ever asks for
+  if (c->mp) {
+    const ncclResult_t r = mp_allreduce(c, sendbuff, recvbuff, count, stream);
+    if (r != ncclSuccess && t_depth > 0 && t_group_error == ncclSuccess) t_group_error = r;
+    return r;
+  }
   Clique &q = *c->q;
   ncclResult_t rc = ncclSuccess;
   unsigned long long seq = 0;

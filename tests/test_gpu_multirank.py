@@ -313,7 +313,8 @@ def _rccl_rank(rank, world, port, q, fused):
     import __graft_entry__ as ge
     pkg = ge.load_package()
     gold = lambda n: np.load(ROOT / "tests" / "golden" / n)
-    e, dt, _ = _engine(pkg, gold, rank)                  # one process per GPU: device = rank
+    # one process per GPU: device = rank (C2R_TEST_ONE_DEVICE: every rank on device 0, for the stand-in librccl)
+    e, dt, _ = _engine(pkg, gold, 0 if os.environ.get("C2R_TEST_ONE_DEVICE") else rank)
     comm = pkg.parallel.RcclComm(e, dist)                # c2r_comm_unique_id on rank 0, gloo carries it, c2r_comm_init
     assert e.rccl_ranks() == world
     got = _iterate(e, dt, 3, fused=fused, first=1 + rank, stride=world)
@@ -339,6 +340,59 @@ def test_two_processes_rccl_vs_oracle(pkg, gold):
             p.start()
         got = collect_from_ranks(procs, q)
         _same_as_oracle(got, ref)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_processes_with_standin_rccl_vs_oracle(pkg, gold, monkeypatch, world):
+    """THE LAUNCH SHAPE OF THE DRIVER -- one process per rank, c2r_create + c2r_comm_init (ncclCommInitRank) through
+    parallel.RcclComm with the id carried by gloo -- executed on the one device: the sums go through the multi-process mode of the
+    stand-in for librccl (tests/fake_rccl.hip, FAKE_RCCL_MULTIPROCESS=1: a clique in POSIX shared memory, the ranks' buffers
+    mapped into the summing process with hipIpcOpenMemHandle, rank-ordered sum).  Three fused iterations and three plain ones
+    against the oracle with the same dealing and association, bit for bit -- what test_two_processes_rccl_vs_oracle will do with
+    the real RCCL once it meets two devices."""
+    from test_gpu_rccl_standin import build_fake, oracle_ranks, same, static_shares
+    sys.path.insert(0, str(ROOT / "tests"))
+    import rccl_standin_worker as w
+    monkeypatch.setenv("C2R_RCCL_LIBRARY", str(build_fake()))
+    monkeypatch.setenv("FAKE_RCCL_MULTIPROCESS", "1")
+    monkeypatch.setenv("C2R_TEST_ONE_DEVICE", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ref = oracle_ranks(pkg, w.case_heating16(pkg), static_shares(3, world), 3)
+    ctx = mp.get_context("spawn")
+    for n, fused in enumerate((True, False)):
+        q = ctx.Queue()
+        port = 35100 + (os.getpid() % 2000) + 10 * world + n
+        procs = [ctx.Process(target=_rccl_rank, args=(r, world, port, q, fused)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = collect_from_ranks(procs, q)
+        same(got, ref, (world, fused))
+
+
+def test_bench_under_torchrun_with_standin_ranks(pkg):
+    """bench.py exactly as the driver launches it for N > 1 -- python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    -- on the one device (C2R_BENCH_SHARE_DEVICE=1), the library's communicator made by parallel.RcclComm over gloo, its sums
+    carried by the multi-process stand-in: the rank glue of bench.py (id broadcast, barrier, max over ranks, gathered per-rank
+    timings, ONE result line from rank 0) runs to the end, and the line says what carried the sum."""
+    import subprocess
+    from test_gpu_rccl_standin import build_fake
+    env = dict(os.environ, C2R_RCCL_LIBRARY=str(build_fake()), FAKE_RCCL_MULTIPROCESS="1", C2R_BENCH_SHARE_DEVICE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 36100 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--mesh", "64", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    (OUT / "bench_torchrun_standin.log").write_text(r.stdout[-5000:] + "\n--- stderr ---\n" + r.stderr[-10000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["sources_per_gpu"] == 8
+    assert d["rccl_ranks"] == 0 and d["rccl_library"].endswith("_fake_rccl.so") and "STAND-IN" in d["config"]["parallelism"]
+    assert "c2r_comm_init = ncclCommInitRank" in d["config"]["parallelism"] and "FALL-BACK" not in d["config"]["parallelism"]
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["config"]["coverage"] > 0.99
+    assert d["value"] > 0 and abs(d["value"] - 64 ** 3 * 16 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
 
 
 def test_all_devices_of_the_node_rccl(pkg, gold):
