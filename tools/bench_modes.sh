@@ -14,6 +14,11 @@ C2R_BENCH_SHARE_DEVICE=1 run share2 python bench.py --gpus 2 --steps 10 --warmup
 for n in 2 4 8; do
   C2R_BENCH_SHARE_DEVICE=1 C2R_COMM_SHARED_DEVICE_RCCL=1 C2R_RCCL_LIBRARY=$PWD/tests/_fake_rccl.so run standin$n python bench.py --gpus $n --steps 4 --warmup 1 --no-cpu-baseline
 done
+# ... and the driver's own launch shape, torch.distributed.run with one process per rank, on this one device: the multi-process
+# mode of the stand-in (FAKE_RCCL_MULTIPROCESS=1; C2R_BENCH_SHARE_DEVICE=1 puts every rank on GPU 0)
+for n in 2 4; do
+  C2R_BENCH_SHARE_DEVICE=1 FAKE_RCCL_MULTIPROCESS=1 C2R_RCCL_LIBRARY=$PWD/tests/_fake_rccl.so run torchrun${n}_standin python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29700 + n)) bench.py --gpus $n --steps 4 --warmup 1 --no-cpu-baseline
+done
 run two_without_second_device python bench.py --gpus 2 --steps 2 --no-cpu-baseline
 run children1 python bench.py --gpus 1 --launcher children --steps 5 --warmup 2 --no-cpu-baseline
 tail -2 "$out/two_without_second_device.err"
