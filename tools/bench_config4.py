@@ -186,6 +186,11 @@ def main():
         hist.append({"call": call_no, "iter": niter, "pass_ms": 1e3 * (t1 - t0), "chem_ms": 1e3 * (t2 - t1), "sweep_kernel_ms": tm.sweep_ms,
                      "rates_kernel_ms": tm.rates_ms, "cells_swept": int(tm.cells_swept), "sweep_launches": tm.sweep_launches,
                      "rates_launches": tm.rates_launches, "nonconv": int(conv), "sum_nbox": int(e.get_loss()[1])})
+        # a line per iteration on stderr: a 512^3 pass takes most of a minute, and a run that prints nothing for minutes is taken
+        # for hung by the GPU pool's watchdog
+        sys.stderr.write(f"bench_config4: iteration {niter}: pass {hist[-1]['pass_ms'] / 1e3:.1f} s, chemistry {hist[-1]['chem_ms'] / 1e3:.2f} s, "
+                         f"{hist[-1]['nonconv']} cells not converged\n")
+        sys.stderr.flush()
         if census:
             hist[-1]["lane_census"] = census
         if shares:
