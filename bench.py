@@ -333,6 +333,11 @@ def main():
         # every rank holds the full source list; rank r sweeps r+1, r+1+world, ... (master_slave.F90:85)
         mat, grid, src, cosmo = config3_inputs(pkg, n, total_src, heating=a.heating, neutral=a.neutral_start)
         batch = a.batch or 8
+    if cfg4 and n >= 256:
+        # the column scratch of a many-source share (a block per source in flight, up to 0.8 GB each at 256^3) is allocated when
+        # the first step begins, in front of the warm-up, instead of piece by piece inside the timed steps: a cold device
+        # allocation costs ~24 ms per GB and stalls every launch of the process
+        os.environ.setdefault("C2R_ARENA_RESERVE_GB", "110")
     tables = pkg.RadiationTables.load()
     e = pkg.HipEngine((n, n, n), devices)
     e.set_tables(tables)
