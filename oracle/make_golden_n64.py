@@ -50,20 +50,21 @@ def main():
     ap.add_argument("--bench-sources", action="store_true")
     ap.add_argument("--iso", action="store_true", help="isothermal run (no temperature grid, no heating rates)")
     ap.add_argument("--omp", type=int, default=0, help="the reference's OpenMP build on this many threads")
+    ap.add_argument("--pl", action="store_true", help="the -DPL -DQUASARS build: sources are i,j,k,S_BB,S_PL,S_QPL")
     ap.add_argument("--check", action="store_true", help="compare with the committed fixture instead of writing it")
     ap.add_argument("--keep", action="store_true", help="keep the run directory (tap dumps)")
     a = ap.parse_args()
     N = a.mesh
     SOURCES = [(32, 32, 32, 1e54)]
     if a.sources:
-        SOURCES = [tuple(float(x) if i == 3 else int(x) for i, x in enumerate(s.split(","))) for s in a.sources]
+        SOURCES = [tuple(float(x) if i >= 3 else int(x) for i, x in enumerate(s.split(","))) for s in a.sources]
     if a.bench_sources:
         SOURCES = bench_sources(N)
-    NAME = f"n{N}_{'iso' if a.iso else 'heat'}_{len(SOURCES)}src"
+    NAME = f"n{N}_{'iso' if a.iso else 'heat'}{'_pl' if a.pl else ''}_{len(SOURCES)}src"
 
-    subprocess.run([str(HERE / "ref_build.sh"), str(N)] + (["omp"] if a.omp else []), check=True)
+    subprocess.run([str(HERE / "ref_build.sh"), str(N)] + (["omp"] if a.omp else []) + (["pl"] if a.pl else []), check=True)
     run = refrun.run_reference(N, SOURCES, isothermal=a.iso, steps_per_slice=1, name="golden_" + NAME,
-                               omp=bool(a.omp), threads=max(1, a.omp), timeout=6 * 3600)
+                               omp=bool(a.omp), threads=max(1, a.omp), timeout=6 * 3600, pl=a.pl)
     conv = refrun.parse_log(run)
     out = {"ncalls": np.int32(len(conv))}
     grids = ["xh", "xhe", "phih_grid", "phihe_grid", "xh_av", "xhe_av"] + ([] if a.iso else ["temperature", "phiheat"])
@@ -72,7 +73,7 @@ def main():
         tout = refrun.read_records(run / "results" / f"tap_{call:04d}_out.bin", mmap=True)
         p = f"c{call}_"
         for k in ["mesh", "dt", "zred", "H0", "Omega0", "dr", "vol", "srcpos", "NormFlux", "S_star", "isothermal",
-                  "temper_val", "clumping", "reccoef"]:
+                  "temper_val", "clumping", "reccoef"] + (["NormFluxPL", "pl_S_star", "NormFluxQPL", "qpl_S_star"] if a.pl else []):
             out[p + k] = np.array(tin[k])
         assert np.all(tin["ndens"] == tin["ndens"][0])
         out[p + "ndens_uniform"] = tin["ndens"][0]

@@ -309,19 +309,11 @@ bool mp_wait(ShmClique *q, double seconds) {
 }
 
 ncclResult_t mp_export(const void *p, hipIpcMemHandle_t *h, size_t *off) {
-  static std::mutex m;
-  static std::map<void *, hipIpcMemHandle_t> cache; // one handle per allocation
+  // (asked for at every collective: an address can belong to another allocation the next time it is seen)
   void *base = nullptr;
   size_t size = 0;
   if (hipMemGetAddressRange(&base, &size, const_cast<void *>(p)) != hipSuccess) return ncclUnhandledCudaError;
-  std::lock_guard<std::mutex> lk(m);
-  auto it = cache.find(base);
-  if (it == cache.end()) {
-    hipIpcMemHandle_t hh;
-    if (hipIpcGetMemHandle(&hh, base) != hipSuccess) return ncclUnhandledCudaError;
-    it = cache.emplace(base, hh).first;
-  }
-  *h = it->second;
+  if (hipIpcGetMemHandle(h, base) != hipSuccess) return ncclUnhandledCudaError;
   *off = (size_t)(static_cast<const char *>(p) - static_cast<const char *>(base));
   return ncclSuccess;
 }

@@ -348,7 +348,8 @@ def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
     e.close()
 
 
-@pytest.mark.parametrize("fixture", ["n64_heat_1src.npz", "n128_heat_2src.npz", "n256_iso_8src.npz", "n128_iso_32src.npz"])
+@pytest.mark.parametrize("fixture", ["n64_heat_1src.npz", "n128_heat_2src.npz", "n256_iso_8src.npz", "n128_iso_32src.npz",
+                                     "n64_heat_pl_3src.npz"])
 def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     """BASELINE configs[1]: 64^3 uniform density, one point source (1e54 photons/s, 5e4 K black body),
     heating on, four consecutive evolve3D calls (83 outer iterations) chained exactly as the
@@ -362,7 +363,9 @@ def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     n128_iso_32src.npz: the shape of BASELINE configs[3] as far as the reference's test problem allows (uniform density): 128^3,
     32 sources of 1e52..1e54 photons/s (log-uniform, seeded), neutral start -- boxes that stop after a few sub-boxes and grow from
     iteration to iteration and from time step to time step: loss probes, tile-list rates launches, blocks that move, against the
-    reference itself (again its OpenMP build)."""
+    reference itself (again its OpenMP build).
+    n64_heat_pl_3src.npz: the physics of BASELINE configs[4] -- heating, black-body + power-law + quasar-like SEDs (the -DPL
+    -DQUASARS build of the reference, its own rad_ini tables) -- at 64^3 with three sources of mixed SEDs."""
     import hashlib
     if not (Path(__file__).parent / "golden" / fixture).exists():
         pytest.skip(f"{fixture} not generated (oracle/make_golden_n64.py)")
@@ -374,6 +377,8 @@ def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     xh = np.repeat(z["c1_xh_uniform"], nc)
     xhe = np.repeat(z["c1_xhe_uniform"], nc)
     temp = None if iso else np.repeat(z["c1_temperature_uniform"].astype(np.float32), nc)
+    if "c1_NormFluxPL" in z.files:
+        tables = pkg.RadiationTables.load().add_sed_file(Path(__file__).parent / "golden" / "rad_tables_pl_qpl.npz")
     ev = pkg.Evolve((n, n, n), tables, device=0)
     log = {}
     for call in range(1, int(z["ncalls"]) + 1):
@@ -382,6 +387,9 @@ def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
                            float(g("clumping")[0]), g("reccoef"))
         grid = pkg.GridProps((n, n, n), tuple(g("dr")), float(g("vol")[0]))
         src = pkg.SourceProps(g("srcpos").reshape(-1, 3), g("NormFlux"), float(g("S_star")[0]))
+        if f"c{call}_NormFluxPL" in z.files:
+            src.NormFluxPL, src.pl_S_star = g("NormFluxPL"), float(g("pl_S_star")[0])
+            src.NormFluxQPL, src.qpl_S_star = g("NormFluxQPL"), float(g("qpl_S_star")[0])
         cosmo = pkg.Cosmology(float(g("zred")[0]), float(g("H0")[0]), float(g("Omega0")[0]))
         niter = ev.evolve3D(0.0, float(g("dt")[0]), 0, mat, grid, src, cosmo)
         assert ev.conv_flags == [int(x) for x in g("conv_flags")], call
