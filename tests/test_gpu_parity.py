@@ -349,7 +349,7 @@ def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
 
 
 @pytest.mark.parametrize("fixture", ["n64_heat_1src.npz", "n128_heat_2src.npz", "n256_iso_8src.npz", "n128_iso_32src.npz",
-                                     "n64_heat_pl_3src.npz"])
+                                     "n64_heat_pl_3src.npz", "n256_heat_8src.npz"])
 def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     """BASELINE configs[1]: 64^3 uniform density, one point source (1e54 photons/s, 5e4 K black body),
     heating on, four consecutive evolve3D calls (83 outer iterations) chained exactly as the
@@ -365,7 +365,8 @@ def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     iteration to iteration and from time step to time step: loss probes, tile-list rates launches, blocks that move, against the
     reference itself (again its OpenMP build).
     n64_heat_pl_3src.npz: the physics of BASELINE configs[4] -- heating, black-body + power-law + quasar-like SEDs (the -DPL
-    -DQUASARS build of the reference, its own rad_ini tables) -- at 64^3 with three sources of mixed SEDs."""
+    -DQUASARS build of the reference, its own rad_ini tables) -- at 64^3 with three sources of mixed SEDs.
+    n256_heat_8src.npz: the benchmark's workload once more, with heating and thermal evolution."""
     import hashlib
     if not (Path(__file__).parent / "golden" / fixture).exists():
         pytest.skip(f"{fixture} not generated (oracle/make_golden_n64.py)")
