@@ -13,6 +13,18 @@
 
 void __real__QMmaster_slave_processingPdo_grid(double *dt, int *niter);
 
+/* Round 5: the non-converged count of every global pass as well, printed when the next pass begins.  global_pass itself is
+ * called from within its own object (no undefined reference for the linker to wrap), but the per-cell routine it calls for
+ * every cell, evolve0D_global(dt,pos,conv_flag) of module evolve_point (files_for_3D/evolve.F90:477-484,
+ * evolve_point.F90:325), is reached across objects: with -Wl,--wrap=_QMevolve_pointPevolve0d_global its running count is seen
+ * after every call; the value after the last cell is the count of the pass. */
+void __real__QMevolve_pointPevolve0d_global(double *dt, int *pos, int *conv_flag);
+static int last_conv_flag = -1;
+void __wrap__QMevolve_pointPevolve0d_global(double *dt, int *pos, int *conv_flag) {
+  __real__QMevolve_pointPevolve0d_global(dt, pos, conv_flag);
+  last_conv_flag = *conv_flag;
+}
+
 static double now(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -23,7 +35,7 @@ void __wrap__QMmaster_slave_processingPdo_grid(double *dt, int *niter) {
   static double last_entry = 0.0;
   static int passes = 0;
   const double t0 = now();
-  if (passes > 0) fprintf(stderr, "pass_timer: iteration %d took %.3f s (entry to entry)\n", passes, t0 - last_entry);
+  if (passes > 0) fprintf(stderr, "pass_timer: iteration %d took %.3f s (entry to entry), non-converged cells %d\n", passes, t0 - last_entry, last_conv_flag);
   const char *stop = getenv("C2R_REF_STOP_AFTER");
   if (stop && passes >= atoi(stop)) {
     fprintf(stderr, "pass_timer: stopping after %d iterations (C2R_REF_STOP_AFTER)\n", passes);

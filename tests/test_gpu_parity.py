@@ -349,7 +349,7 @@ def test_photon_statistics_on_device(pkg, tables, gold, fname, call):
 
 
 @pytest.mark.parametrize("fixture", ["n64_heat_1src.npz", "n128_heat_2src.npz", "n256_iso_8src.npz", "n128_iso_32src.npz",
-                                     "n64_heat_pl_3src.npz", "n256_heat_8src.npz"])
+                                     "n64_heat_pl_3src.npz"])
 def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     """BASELINE configs[1]: 64^3 uniform density, one point source (1e54 photons/s, 5e4 K black body),
     heating on, four consecutive evolve3D calls (83 outer iterations) chained exactly as the
@@ -365,8 +365,7 @@ def test_config2_point_sources_vs_reference(pkg, tables, gold, fixture):
     iteration to iteration and from time step to time step: loss probes, tile-list rates launches, blocks that move, against the
     reference itself (again its OpenMP build).
     n64_heat_pl_3src.npz: the physics of BASELINE configs[4] -- heating, black-body + power-law + quasar-like SEDs (the -DPL
-    -DQUASARS build of the reference, its own rad_ini tables) -- at 64^3 with three sources of mixed SEDs.
-    n256_heat_8src.npz: the benchmark's workload once more, with heating and thermal evolution."""
+    -DQUASARS build of the reference, its own rad_ini tables) -- at 64^3 with three sources of mixed SEDs."""
     import hashlib
     if not (Path(__file__).parent / "golden" / fixture).exists():
         pytest.skip(f"{fixture} not generated (oracle/make_golden_n64.py)")
@@ -1449,3 +1448,33 @@ def test_scratch_reserved_before_the_first_iteration(pkg, tables, monkeypatch):
     for k in ("phih_grid", "phihe_grid", "xh_av", "xhe_av", "xh_intermed", "xhe_intermed"):
         assert np.array_equal(out[0][k], out[1][k]), k
     assert out[0]["sum_nbox"] == out[1]["sum_nbox"]
+
+
+def test_benchmark_workload_with_heating_vs_the_serial_reference(pkg, tables, gold):
+    """BASELINE configs[2] WITH HEATING at 256^3: the first nine outer iterations of the reference's SERIAL build (a whole serial
+    call is 52 iterations of up to ten minutes; oracle/make_golden_first_iterations.py) -- the non-converged count after every
+    global pass, the numbers evolve3D's exit test reads.  The reference's OpenMP build, which wrote the isothermal 256^3 fixture
+    bit for bit like the serial one, does NOT agree with the serial build here: from the eighth iteration on it counts 1892544 /
+    2132060 cells where the serial build (and this library, and the oracle) count 1892540 / 2132062 -- a whole-call fixture written
+    by it (make_golden_n64.py 256 --bench-sources --omp 8, 2.3 h) had to be discarded; its own history is kept in the file for the
+    record."""
+    z = gold("n256_heat_8src_first9.npz")
+    n = int(z["c1_mesh"][0])
+    nc = n ** 3
+    g = lambda k: z["c1_" + k]
+    mat = pkg.Material(np.full(nc, float(g("ndens_uniform"))), np.repeat(g("xh_uniform"), nc), np.repeat(g("xhe_uniform"), nc),
+                       np.repeat(g("temperature_uniform").astype(np.float32), nc), False, float(g("temper_val")[0]),
+                       float(g("clumping")[0]), g("reccoef"))
+    grid = pkg.GridProps((n, n, n), tuple(g("dr")), float(g("vol")[0]))
+    src = pkg.SourceProps(g("srcpos").reshape(-1, 3), g("NormFlux"), float(g("S_star")[0]))
+    cosmo = pkg.Cosmology(float(g("zred")[0]), float(g("H0")[0]), float(g("Omega0")[0]))
+    e = engine_for(pkg, (n, n, n), mat, grid, src, cosmo, tables)
+    e.begin_step()
+    conv = []
+    for _ in range(len(z["conv_flags_serial"])):
+        e.set_rates_to_zero()
+        e.pass_sources(1, 1)
+        conv.append(e.global_pass(float(g("dt")[0])))
+    e.close()
+    assert conv == [int(x) for x in z["conv_flags_serial"]]
+    assert conv[:7] == [int(x) for x in z["conv_flags_openmp"][:7]] and conv[7] != int(z["conv_flags_openmp"][7])

@@ -183,3 +183,50 @@ def test_shell_order_parallel_sweep_equals_serial_sweep(orc, otables, pkg, n, ns
     assert ca == cb and np.array_equal(a.xh_av, b.xh_av) and np.array_equal(a.xhe_intermed, b.xhe_intermed)
     if not iso:
         assert np.array_equal(a.temperature, b.temperature)
+
+
+@pytest.mark.parametrize("fixture", ["n64_heat_1src.npz", "n128_iso_32src.npz"])
+def test_oracle_against_the_larger_reference_fixtures(orc, otables, pkg, gold, fixture):
+    """The oracle itself against the reference's larger runs (tests/golden/n64_heat_1src.npz: BASELINE configs[1], 83 outer
+    iterations with heating; n128_iso_32src.npz: 32 faint sources at 128^3, 149 outer iterations with growing sub-boxes): same
+    iteration history, same SHA-256 of every grid after every call -- the pins of the oracle at sizes beyond the 16^3 / 22^3 tap
+    fixtures.  Minutes of CPU time: runs with C2R_ORACLE_LARGE=1 (DESIGN.md section 4 records the last run)."""
+    import hashlib
+    import os
+    if not os.environ.get("C2R_ORACLE_LARGE"):
+        pytest.skip("set C2R_ORACLE_LARGE=1 (minutes of CPU time)")
+    z = gold(fixture)
+    n = int(z["c1_mesh"][0])
+    nc = n ** 3
+    iso = bool(z["c1_isothermal"][0])
+    nthreads = min(8, os.cpu_count() or 1)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    xh, xhe = np.repeat(z["c1_xh_uniform"], nc), np.repeat(z["c1_xhe_uniform"], nc)
+    temp = None if iso else np.repeat(z["c1_temperature_uniform"].astype(np.float32), nc)
+    for call in range(1, int(z["ncalls"]) + 1):
+        g = lambda k: z[f"c{call}_{k}"]
+        st = orc.Step((n, n, n), g("dr"), g("vol")[0], g("zred")[0], g("H0")[0], g("Omega0")[0], iso, g("temper_val")[0],
+                      g("clumping")[0], g("srcpos"), g("NormFlux"), g("S_star")[0], np.full(nc, float(g("ndens_uniform"))), g("reccoef"))
+        s = orc.State(st, xh, xhe, temp)
+        orc.begin_step(s)
+        dt = float(g("dt")[0])
+        crit = min(int(np.float32(2.5e-4) * nc), st.c.nsrc)                        # evolve.F90:147
+        it, conv, flags = 0, nc, []
+        while not (conv < crit and it > 1) and it <= 500:                        # :163, :177
+            it += 1
+            orc.pass_all_sources_shells(otables, st, s, nthreads)
+            conv = orc.global_pass_threads(otables, st, s, dt, nthreads)
+            flags.append(conv)
+        assert flags == [int(x) for x in g("conv_flags")], call
+        if conv < crit:                                                           # :164-166: the final copy
+            s.xh[:], s.xhe[:] = s.xh_intermed, s.xhe_intermed
+            if temp is not None:
+                s.temperature[2 * nc:] = s.temperature[:nc]
+        got = {"xh": s.xh, "xhe": s.xhe, "phih_grid": s.phih, "phihe_grid": s.phihe, "xh_av": s.xh_av, "xhe_av": s.xhe_av}
+        if not iso:
+            got.update(temperature=s.temperature, phiheat=s.phiheat)
+        for k, v in got.items():
+            assert sha(v) == str(g("sha_" + k)), (call, k)
+        assert int(s.c.sum_nbox) == int(g("sum_nbox")[0])
+        xh, xhe = s.xh.copy(), s.xhe.copy()
+        temp = None if iso else s.temperature.copy()
