@@ -10,7 +10,7 @@ every pass), and, for the record, the same with the OpenMP build.  The two DIFFE
 (in isothermal runs it is, bit for bit: make_golden_n64.py --check, tests/golden/n256_iso_8src.npz), so the fixture written by
 `make_golden_n64.py 256 --bench-sources --omp 8` (heating) is NOT a golden vector; only its inputs are used here.
 
-    python oracle/make_golden_first_iterations.py tests/golden/n256_heat_8src_first9.npz 9     (~25 min; the scalars evolve3D
+    python oracle/make_golden_first_iterations.py tests/golden/n256_heat_8src_first14.npz 9     (~25 min; the scalars evolve3D
     read -- c1_dt, c1_dr, c1_vol, c1_zred, ... -- are taken from the fixture given, which may be the one being rewritten)
 """
 import os

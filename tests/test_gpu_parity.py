@@ -1451,14 +1451,14 @@ def test_scratch_reserved_before_the_first_iteration(pkg, tables, monkeypatch):
 
 
 def test_benchmark_workload_with_heating_vs_the_serial_reference(pkg, tables, gold):
-    """BASELINE configs[2] WITH HEATING at 256^3: the first nine outer iterations of the reference's SERIAL build (a whole serial
+    """BASELINE configs[2] WITH HEATING at 256^3: the first fourteen outer iterations of the reference's SERIAL build (a whole serial
     call is 52 iterations of up to ten minutes; oracle/make_golden_first_iterations.py) -- the non-converged count after every
     global pass, the numbers evolve3D's exit test reads.  The reference's OpenMP build, which wrote the isothermal 256^3 fixture
     bit for bit like the serial one, does NOT agree with the serial build here: from the eighth iteration on it counts 1892544 /
     2132060 cells where the serial build (and this library, and the oracle) count 1892540 / 2132062 -- a whole-call fixture written
     by it (make_golden_n64.py 256 --bench-sources --omp 8, 2.3 h) had to be discarded; its own history is kept in the file for the
     record."""
-    z = gold("n256_heat_8src_first9.npz")
+    z = gold("n256_heat_8src_first14.npz")
     n = int(z["c1_mesh"][0])
     nc = n ** 3
     g = lambda k: z["c1_" + k]
