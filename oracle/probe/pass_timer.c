@@ -20,6 +20,8 @@ void __real__QMmaster_slave_processingPdo_grid(double *dt, int *niter);
  * after every call; the value after the last cell is the count of the pass. */
 void __real__QMevolve_pointPevolve0d_global(double *dt, int *pos, int *conv_flag);
 static int last_conv_flag = -1;
+/* ... and the sub-boxes all sources of the pass needed (module variable sum_nbox of evolve_source, evolve_source.F90:236) */
+extern int _QMevolve_sourceEsum_nbox;
 void __wrap__QMevolve_pointPevolve0d_global(double *dt, int *pos, int *conv_flag) {
   __real__QMevolve_pointPevolve0d_global(dt, pos, conv_flag);
   last_conv_flag = *conv_flag;
@@ -45,6 +47,6 @@ void __wrap__QMmaster_slave_processingPdo_grid(double *dt, int *niter) {
   last_entry = t0;
   __real__QMmaster_slave_processingPdo_grid(dt, niter);
   passes++;
-  fprintf(stderr, "pass_timer: pass %d (niter %d) took %.3f s\n", passes, *niter, now() - t0);
+  fprintf(stderr, "pass_timer: pass %d (niter %d) took %.3f s, sum_nbox %d\n", passes, *niter, now() - t0, _QMevolve_sourceEsum_nbox);
   fflush(stderr);
 }
